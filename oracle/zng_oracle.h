@@ -1,0 +1,90 @@
+/* zng_oracle.h -- CPU restatement of zlib-ng's functable hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.  The
+ * product (zlib-ng_amd/, include/) never links or calls it.
+ *
+ * Every function restates the algorithm of one reference function (zlib-ng
+ * 2.2.2); the reference file:line it follows is cited at each definition.
+ * Parity pinning (see oracle/README.md): the reference's own known-answer
+ * vectors (tests/golden/, extracted from test/test_adler32.cc,
+ * test/test_crc32.cc, test/infcover.c ...) plus oracle/_ref (the reference's
+ * arch/generic/crc32_braid_c.c compiled from its own sources).
+ */
+#ifndef ZNG_ORACLE_H
+#define ZNG_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Adler-32 (adler32.c, adler32_p.h, arch/generic/adler32_c.c) ------- */
+uint32_t oracle_adler32(uint32_t adler, const uint8_t *buf, size_t len);
+uint32_t oracle_adler32_fold_copy(uint32_t adler, uint8_t *dst, const uint8_t *src, size_t len);
+uint32_t oracle_adler32_combine(uint32_t adler1, uint32_t adler2, int64_t len2);
+
+/* ---- CRC-32 (crc32.c, arch/generic/crc32_braid_c.c, crc32_braid_comb*.c) */
+typedef struct oracle_crc32_fold_s {
+    uint8_t  fold[64];      /* crc32.h:8-14: only SIMD variants use fold[] */
+    uint32_t value;
+} oracle_crc32_fold_t;
+
+uint32_t oracle_crc32_braid(uint32_t crc, const uint8_t *buf, size_t len);
+uint32_t oracle_crc32_bytewise(uint32_t crc, const uint8_t *buf, size_t len);
+uint32_t oracle_crc32(uint32_t crc, const uint8_t *buf, size_t len);   /* export layer: NULL -> 0 */
+uint32_t oracle_crc32_fold_reset(oracle_crc32_fold_t *crc);
+void     oracle_crc32_fold(oracle_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc);
+void     oracle_crc32_fold_copy(oracle_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len);
+uint32_t oracle_crc32_fold_final(oracle_crc32_fold_t *crc);
+uint32_t oracle_multmodp(uint32_t a, uint32_t b);
+uint32_t oracle_x2nmodp(int64_t n, unsigned k);
+uint32_t oracle_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
+uint32_t oracle_crc32_combine_gen(int64_t len2);
+uint32_t oracle_crc32_combine_op(uint32_t crc1, uint32_t crc2, uint32_t op);
+const uint32_t *oracle_get_crc_table(void);
+
+/* ---- deflate-side primitives (deflate.h state subset) ------------------ */
+#define ORACLE_HASH_SIZE 65536u
+#define ORACLE_STD_MIN_MATCH 3
+#define ORACLE_STD_MAX_MATCH 258
+#define ORACLE_MIN_LOOKAHEAD (ORACLE_STD_MAX_MATCH + ORACLE_STD_MIN_MATCH + 1)
+
+typedef uint16_t oracle_pos;
+
+/* The subset of deflate_state (deflate.h:144-334) the hot-path kernels touch
+ * (SURVEY.md section 8 a13). */
+typedef struct oracle_deflate_state {
+    uint32_t    w_size, w_bits, w_mask;
+    uint32_t    lookahead;
+    uint32_t    window_size;
+    uint8_t    *window;
+    oracle_pos *prev;
+    oracle_pos *head;
+    uint32_t    strstart;
+    uint32_t    match_start;
+    uint32_t    prev_length;
+    uint32_t    max_chain_length;
+    uint32_t    good_match;
+    int32_t     nice_match;
+    int32_t     level;
+} oracle_deflate_state;
+
+void       oracle_slide_hash(oracle_deflate_state *s);
+uint32_t   oracle_compare256(const uint8_t *src0, const uint8_t *src1);
+uint32_t   oracle_update_hash(uint32_t h, uint32_t val);
+oracle_pos oracle_quick_insert_string(oracle_deflate_state *s, uint32_t str);
+void       oracle_insert_string(oracle_deflate_state *s, uint32_t str, uint32_t count);
+uint32_t   oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match);
+
+/* ---- inflate-side primitives (chunkset_tpl.h) -------------------------- */
+uint32_t   oracle_chunksize(void);
+uint8_t   *oracle_chunkmemset_safe(uint8_t *out, uint8_t *from, unsigned len, unsigned left);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZNG_ORACLE_H */
