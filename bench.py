@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the arch/rocm hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): crc32 + adler32 over a 1 GiB synthetic buffer that is
+already resident in HBM, block-parallel with on-device combine.  One "step" = one fused pass
+of `zng_rocm_adler32_crc32_dev` over the rank's 1 GiB shard (both checksums, bytes read once).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+N > 1: weak scaling -- every rank owns its own 1 GiB shard of one N GiB logical buffer; the only
+exchange is the all-gather of {adler, crc, len} (12 bytes per rank over RCCL) followed by the
+ordered on-device combine.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+METRIC = "GB/s input throughput (adler32, crc32, deflate lvl6, inflate) @1/2/4/8 GPU vs CPU ref"
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHARD_BYTES = 1 << 30           # cfg2: 1 GiB per GPU
+SEED = 0x5EED0002
+
+
+def cpu_baseline(host_view, reps=3):
+    """oracle (port of adler32_c) + oracle/_ref (the reference's crc32_braid_c.c) on ONE host core,
+    over the same bytes the GPU step reads."""
+    import oracle_lib
+    orc = oracle_lib.load()
+    ref_crc = oracle_lib.load_ref_crc32()
+    crc_fn = ref_crc if ref_crc is not None else orc.oracle_crc32_braid
+    n = host_view.size
+    ptr = host_view.ctypes.data
+    pair, ta, tc = [], [], []
+    a = c = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        a = orc.oracle_adler32(1, ptr, n)
+        t1 = time.perf_counter()
+        c = crc_fn(0, ptr, n)
+        t2 = time.perf_counter()
+        ta.append(t1 - t0)
+        tc.append(t2 - t1)
+        pair.append(t2 - t0)
+    gb = n / 1e9
+    return {
+        "value": round(gb / statistics.median(pair), 3),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": ("%d MiB of the step's own buffer, %d reps, median; one thread runs adler32 (oracle port of "
+                   "adler32_c.c) then crc32 (%s)" % (n >> 20, reps,
+                                                     "reference crc32_braid_c.c via oracle/_ref" if ref_crc is not None
+                                                     else "oracle port of crc32_braid_c.c")),
+        "adler32_GBps": round(gb / statistics.median(ta), 3),
+        "crc32_GBps": round(gb / statistics.median(tc), 3),
+    }, (a, c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shard-mib", type=int, default=SHARD_BYTES >> 20)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    zr = importlib.import_module("zlib-ng_amd")      # raises if libzng_rocm.so is missing: no fallback
+    zr.init(local_rank)
+
+    n = args.shard_mib << 20
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + rank)
+    buf = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=gen)
+    out = torch.zeros(2, dtype=torch.int32, device=dev)
+    gathered = torch.zeros(world * 4, dtype=torch.int64, device=dev)
+    mine = torch.zeros(4, dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def step():
+        zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
+        if world > 1:
+            # exchange: {adler, crc, len} per rank, then the ordered combine on device
+            mine[0:2] = out.to(torch.int64) & 0xffffffff
+            mine[2] = n
+            dist.all_gather_into_tensor(gathered, mine)
+            g = gathered.view(world, 4)
+            lens = g[:, 2].contiguous()
+            zr.adler32_combine_dev(g[:, 0].to(torch.int32).contiguous(), lens, total[0:1])
+            zr.crc32_combine_dev(g[:, 1].to(torch.int32).contiguous(), lens, total[1:2])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    zr.trace_begin(args.steps)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = zr.trace_end(args.steps)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    result = [v & 0xffffffff for v in out.tolist()]
+    # separate single-checksum timings (outside the timed region, informational)
+    extra = {}
+    for name, fn in (("adler32", lambda: zr.adler32_dev(buf, out)), ("crc32", lambda: zr.crc32_dev(buf, out))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        zr.trace_begin(20)
+        for _ in range(20):
+            fn()
+        ms = zr.trace_end(20)
+        extra[name + "_kernel_GBps"] = round(n / 1e9 / (statistics.mean(ms) / 1e3), 1)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n / 1e9 / (elapsed / args.steps)
+        k_avg_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
+        achieved = n / 1e9 / (k_avg_ms / 1e3)
+        line = {
+            "metric": METRIC,
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: crc32 + adler32 over a %d MiB synthetic buffer per GPU, HBM-resident, "
+                            "fused single pass + on-device combine" % (n >> 20),
+                "bytes_per_gpu": n,
+                "parallelism": "shard%d+allgather(12B)" % world if world > 1 else "single",
+                "checksums": ["%08x" % result[0], "%08x" % result[1]],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "zr::stream_kernel<adler,crc> (fused pass)",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": n,
+                "avg_kernel_ms": round(k_avg_ms, 5),
+                "launches_timed": len(kernel_ms),
+            },
+        }
+        line.update(extra)
+        if not args.no_cpu:
+            host = buf.cpu().numpy()
+            cb, (a, c) = cpu_baseline(host)
+            assert [a, c] == result, "GPU result differs from the CPU checker: %r vs %r" % (result, [a, c])
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/* zng_rocm.h -- C ABI of the MI355X (gfx950) backend for zlib-ng's functable hot path.
+ *
+ * This is the drop-in boundary: a plain C shared library (libzng_rocm.so, built
+ * by hipcc from zlib-ng_amd/csrc) whose entry points are what zlib-ng's own
+ * dispatch boundary -- `struct functable_s`, functable.h:26-42 -- would bind for
+ * an `arch/rocm` backend.  Pointers and sizes only; no C++/torch types.
+ * INTEGRATION.md shows the reference-side stub (functable.c / arch/rocm) that
+ * calls these.
+ *
+ * Two families of entry points:
+ *
+ *  1. `zng_rocm_<slot>`: the functable slot itself, same argument meaning as the
+ *     reference slot, HOST pointers.  Data is staged to the device, the HIP
+ *     kernel runs, the answer comes back.  They never compute on the CPU: if the
+ *     device is unusable they abort() with a message (a functable slot has no
+ *     error channel; the integration stub only installs them after
+ *     zng_rocm_init() returned 0, and keeps zlib-ng's own CPU tier for calls
+ *     below its size threshold).
+ *
+ *  2. `zng_rocm_<slot>_dev`: the same operation on data ALREADY RESIDENT IN HBM
+ *     (device pointers), asynchronous on a caller-supplied HIP stream
+ *     (`void *stream` is a hipStream_t; NULL = the default stream).  Results are
+ *     written to device memory.  This is the measured hot path (bench.py) and
+ *     what a stream-level offload (DEFLATE_HOOK / INFLATE_TYPEDO_HOOK,
+ *     deflate.c:72-106, inflate_p.h:11-41) calls with its device-resident window.
+ *
+ * All functions return 0 on success or a negative ZNG_ROCM_E* code unless they
+ * mirror a reference signature that returns a value.
+ */
+#ifndef ZNG_ROCM_H
+#define ZNG_ROCM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZNG_ROCM_OK          0
+#define ZNG_ROCM_ENODEV     (-1)   /* no usable gfx950 device / HIP runtime error at init */
+#define ZNG_ROCM_EHIP       (-2)   /* a HIP call failed; see zng_rocm_last_error() */
+#define ZNG_ROCM_EINVAL     (-3)   /* bad argument */
+#define ZNG_ROCM_ENOMEM     (-4)
+
+/* ---- lifecycle --------------------------------------------------------- */
+/* Replaces: the feature probe an arch backend adds to cpu_features
+ * (cpu_features.h:23-37, x86_features.c:69-117).  Idempotent, thread-safe.
+ * Builds the constant tables in HBM for `device` (-1 = current device). */
+int         zng_rocm_init(int device);
+int         zng_rocm_available(void);          /* 1 after a successful init */
+int         zng_rocm_device_count(void);       /* 0 when there is no GPU; never aborts */
+const char *zng_rocm_last_error(void);
+/* {CUs, LDS bytes per CU, wavefront size, XCDs} of the initialised device */
+int         zng_rocm_device_info(int32_t out[4]);
+int         zng_rocm_shutdown(void);
+
+/* ---- functable slots, host pointers (functable.h:26-42) ---------------- */
+/* slot `adler32`: arch/generic/adler32_c.c:11-54 */
+uint32_t zng_rocm_adler32(uint32_t adler, const uint8_t *buf, size_t len);
+/* slot `adler32_fold_copy`: arch/generic/adler32_fold_c.c:11-15 */
+uint32_t zng_rocm_adler32_fold_copy(uint32_t adler, uint8_t *dst, const uint8_t *src, size_t len);
+/* slot `crc32`: arch/generic/crc32_braid_c.c:62-216 */
+uint32_t zng_rocm_crc32(uint32_t crc, const uint8_t *buf, size_t len);
+
+/* slots `crc32_fold_reset/_fold/_fold_copy/_fold_final`:
+ * arch/generic/crc32_fold_c.c:10-31 over struct crc32_fold_s (crc32.h:8-14). */
+typedef struct zng_rocm_crc32_fold_s {
+    uint8_t  fold[64];
+    uint32_t value;
+} zng_rocm_crc32_fold_t;
+uint32_t zng_rocm_crc32_fold_reset(zng_rocm_crc32_fold_t *crc);
+void     zng_rocm_crc32_fold(zng_rocm_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc);
+void     zng_rocm_crc32_fold_copy(zng_rocm_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len);
+uint32_t zng_rocm_crc32_fold_final(zng_rocm_crc32_fold_t *crc);
+
+/* ---- checksums on device-resident data --------------------------------- */
+/* d_out: device pointer to one uint32_t.  Same value as the slot on the same
+ * bytes and seed (bit-exact), including len == 0. */
+int zng_rocm_adler32_dev(uint32_t adler, const void *d_buf, size_t len, uint32_t *d_out, void *stream);
+int zng_rocm_crc32_dev(uint32_t crc, const void *d_buf, size_t len, uint32_t *d_out, void *stream);
+/* One pass over the bytes, both checksums: d_out[0] = adler32, d_out[1] = crc32.
+ * (What inflate's inf_chksum / deflate's read_buf need for a gzip+zlib pair,
+ * inflate.c:25-49, deflate.c:1190-1212; BASELINE.json configs[1].) */
+int zng_rocm_adler32_crc32_dev(uint32_t adler, uint32_t crc, const void *d_buf, size_t len,
+                               uint32_t *d_out2, void *stream);
+/* fold_copy on device: checksum `len` bytes of d_src while copying them to
+ * d_dst (2N bytes of traffic).  which: 1 = adler32, 2 = crc32, 3 = both
+ * (d_out2[0] adler, d_out2[1] crc; unused entries untouched). */
+int zng_rocm_fold_copy_dev(int which, uint32_t adler, uint32_t crc, void *d_dst, const void *d_src,
+                           size_t len, uint32_t *d_out2, void *stream);
+
+/* combine operators, computed ON DEVICE from device-resident operands
+ * (adler32.c:32-54 adler32_combine_, crc32_braid_comb.c:16-18 crc32_combine_):
+ * folds `count` consecutive blocks {check[i], len[i]} left to right into one
+ * checksum.  d_checks/d_lens are device arrays; d_out one uint32_t. */
+int zng_rocm_adler32_combine_dev(const uint32_t *d_checks, const uint64_t *d_lens, size_t count,
+                                 uint32_t *d_out, void *stream);
+int zng_rocm_crc32_combine_dev(const uint32_t *d_checks, const uint64_t *d_lens, size_t count,
+                               uint32_t *d_out, void *stream);
+
+/* host-side scalar forms with the reference's exact semantics
+ * (zng_adler32_combine adler32.c:66-68; zng_crc32_combine/_gen/_op
+ * crc32_braid_comb.c:44-54) -- used by the multi-GPU aggregate. */
+uint32_t zng_rocm_adler32_combine(uint32_t adler1, uint32_t adler2, int64_t len2);
+uint32_t zng_rocm_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
+uint32_t zng_rocm_crc32_combine_gen(int64_t len2);
+uint32_t zng_rocm_crc32_combine_op(uint32_t crc1, uint32_t crc2, uint32_t op);
+
+/* ---- measurement hooks --------------------------------------------------
+ * Between trace_begin and trace_end every launch of the DOMINANT kernel of a
+ * *_dev entry point (the streaming kernel, not its finalize step) is bracketed
+ * by a pair of HIP events recorded on the stream the kernel is launched on.
+ * trace_end synchronises, writes the per-launch durations (ms) into `ms_out`
+ * (up to `cap`) and returns how many launches were recorded (negative = error).
+ * Used by bench.py for the roofline figure; no reference counterpart (the
+ * reference measures with Google Benchmark, test/benchmarks/). */
+int zng_rocm_trace_begin(int max_launches);
+int zng_rocm_trace_end(float *ms_out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZNG_ROCM_H */

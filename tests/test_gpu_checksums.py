@@ -1,0 +1,189 @@
+"""GPU parity: HIP Adler-32 / CRC-32 (through the C ABI) vs the CPU oracle.
+
+Bit-exact is the bar (integer work).  Layers:
+  * the reference's own KAT tables through the host-pointer functable slots,
+  * seeded random buffers, every 16-byte phase, ragged lengths, odd seeds, through the
+    device-resident entry points,
+  * BASELINE.json sizes (64 MiB, 1 GiB) against the oracle and through the size-independent
+    property "combine of per-block checksums == one-shot" (fuzzer_checksum.c:33-75).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import product, seeded_bytes, to_dev, torch_mod
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def zr():
+    m = product()
+    m.init()
+    assert m.available()
+    return m
+
+
+def _rows(name):
+    return json.load(open(os.path.join(HERE, "golden", name)))["rows"]
+
+
+def test_adler32_slot_reference_kats(zr):
+    for r in _rows("adler32_kat.json"):
+        data = None if r["data_hex"] is None else bytes.fromhex(r["data_hex"])
+        assert zr.adler32_z(r["seed"], data, r["len"]) == r["expect"], r
+
+
+def test_crc32_slot_reference_kats(zr):
+    for r in _rows("crc32_kat.json"):
+        data = None if r["data_hex"] is None else bytes.fromhex(r["data_hex"])
+        if data is not None and r["len"] == 0:
+            got = zr.crc32_z(r["seed"], data, 0)
+        else:
+            got = zr.crc32_z(r["seed"], data, r["len"])
+        assert got == r["expect"], r
+
+
+SIZES = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 4095, 4096, 5551, 5552, 5553,
+         16383, 16384, 16385, 16384 * 3 + 5, 65536, 100000, 16384 * 256, 16384 * 257 + 4093,
+         (1 << 22) + 1, 16384 * 1300 + 77]
+SEEDS = [(1, 0), (0, 0xffffffff), (0xdeadc0de, 0xdeadbeef), (0xffffffff, 0x12345678)]
+
+
+def test_dev_random_sizes_phases_seeds(zr, oracle):
+    torch = torch_mod()
+    big = seeded_bytes(16384 * 1300 + 77 + 64, 42)
+    dbig = to_dev(big)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for i, n in enumerate(SIZES):
+        for phase in sorted({0, 1, 7, 15, (i * 5) % 16}):
+            for (sa, sc) in SEEDS[: 2 if n > 100000 else 4]:
+                host_ptr = big.ctypes.data + phase
+                want_a = oracle.oracle_adler32(sa, host_ptr, n) if n != 1 or True else 0
+                want_c = oracle.oracle_crc32_braid(sc, host_ptr, n)
+                zr.adler32_dev(dbig, out, adler=sa, length=n, offset=phase)
+                got_a = out[0].item() & 0xffffffff
+                zr.crc32_dev(dbig, out, crc=sc, length=n, offset=phase)
+                got_c = out[0].item() & 0xffffffff
+                zr.adler32_crc32_dev(dbig, out, adler=sa, crc=sc, length=n, offset=phase)
+                both = [v & 0xffffffff for v in out.tolist()]
+                assert got_a == want_a, (n, phase, hex(sa))
+                assert got_c == want_c, (n, phase, hex(sc))
+                assert both == [want_a, want_c], (n, phase)
+
+
+def test_dev_structured_inputs(zr, oracle):
+    """all-zero, all-0xff and ramp inputs (overflow corners of the lane sums)"""
+    torch = torch_mod()
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    n = 16384 * 520 + 123
+    for fill in ("zero", "ff", "ramp"):
+        if fill == "zero":
+            arr = np.zeros(n, dtype=np.uint8)
+        elif fill == "ff":
+            arr = np.full(n, 255, dtype=np.uint8)
+        else:
+            arr = (np.arange(n) % 251).astype(np.uint8)
+        d = to_dev(arr)
+        zr.adler32_crc32_dev(d, out, adler=1, crc=0)
+        got = [v & 0xffffffff for v in out.tolist()]
+        assert got == [oracle.oracle_adler32(1, arr.ctypes.data, n), oracle.oracle_crc32_braid(0, arr.ctypes.data, n)]
+
+
+def test_fold_copy_dev(zr, oracle):
+    torch = torch_mod()
+    src = seeded_bytes(16384 * 70 + 999, 7)
+    dsrc = to_dev(src)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for n, phase in ((0, 0), (5, 3), (16384 * 70 + 900, 9), (16384 * 64, 0), (40000, 15)):
+        ddst = torch.full((n + 64,), 0xAA, dtype=torch.uint8, device="cuda")
+        zr.fold_copy_dev(3, ddst, dsrc, out, adler=1, crc=0, length=n, src_offset=phase, dst_offset=16 + phase)
+        got = [v & 0xffffffff for v in out.tolist()]
+        hp = src.ctypes.data + phase
+        assert got == [oracle.oracle_adler32(1, hp, n), oracle.oracle_crc32_braid(0, hp, n)]
+        back = ddst.cpu().numpy()
+        assert (back[16 + phase:16 + phase + n] == src[phase:phase + n]).all()
+        assert (back[:16 + phase] == 0xAA).all() and (back[16 + phase + n:] == 0xAA).all()
+    # host-pointer slots
+    val, copied = zr.adler32_fold_copy(1, src[:50001])
+    assert val == oracle.oracle_adler32(1, src.ctypes.data, 50001) and copied == src[:50001].tobytes()
+    st = zr.Crc32Fold()
+    st.fold(src[:777])
+    assert st.fold_copy(src[777:9000]) == src[777:9000].tobytes()
+    assert st.final() == oracle.oracle_crc32_braid(0, src.ctypes.data, 9000)
+
+
+def test_combine_dev_matches_oracle_fold(zr, oracle):
+    torch = torch_mod()
+    rng = np.random.default_rng(3)
+    data = seeded_bytes(3_000_000, 11)
+    for count in (0, 1, 2, 7, 1024, 1025, 3000):
+        cuts = np.sort(rng.integers(0, data.size + 1, size=max(count - 1, 0)))
+        edges = np.concatenate(([0], cuts, [data.size])) if count else np.array([0], dtype=np.int64)
+        lens = np.diff(edges).astype(np.uint64) if count else np.zeros(0, dtype=np.uint64)
+        a_chk = np.zeros(count, dtype=np.uint32)
+        c_chk = np.zeros(count, dtype=np.uint32)
+        for i in range(count):
+            p = data.ctypes.data + int(edges[i])
+            a_chk[i] = oracle.oracle_adler32(1, p, int(lens[i]))
+            c_chk[i] = oracle.oracle_crc32_braid(0, p, int(lens[i]))
+        # oracle left fold
+        wa, wc = 1, 0
+        for i in range(count):
+            wa = oracle.oracle_adler32_combine(wa, int(a_chk[i]), int(lens[i]))
+            wc = oracle.oracle_crc32_combine(wc, int(c_chk[i]), int(lens[i]))
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        d_lens = torch.from_numpy(lens.view(np.int64)).cuda()
+        zr.adler32_combine_dev(torch.from_numpy(a_chk.view(np.int32)).cuda(), d_lens, out)
+        ga = out[0].item() & 0xffffffff
+        zr.crc32_combine_dev(torch.from_numpy(c_chk.view(np.int32)).cuda(), d_lens, out)
+        gc = out[0].item() & 0xffffffff
+        assert (ga, gc) == (wa, wc), count
+        if count:
+            assert wa == oracle.oracle_adler32(1, data.ctypes.data, data.size)
+            assert wc == oracle.oracle_crc32_braid(0, data.ctypes.data, data.size)
+        # host scalar forms agree with the oracle's
+        if count >= 2:
+            assert zr.adler32_combine(int(a_chk[0]), int(a_chk[1]), int(lens[1])) == \
+                oracle.oracle_adler32_combine(int(a_chk[0]), int(a_chk[1]), int(lens[1]))
+            assert zr.crc32_combine(int(c_chk[0]), int(c_chk[1]), int(lens[1])) == \
+                oracle.oracle_crc32_combine(int(c_chk[0]), int(c_chk[1]), int(lens[1]))
+
+
+@pytest.mark.parametrize("mib", [64, 1024])
+def test_baseline_sizes(zr, oracle, mib):
+    """cfg1 (64 MiB) and cfg2 (1 GiB): one-shot vs oracle, and block-combine == one-shot."""
+    torch = torch_mod()
+    n = mib << 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x5EED0002)
+    d = torch.randint(0, 256, (n + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for phase in (0, 3):
+        zr.adler32_crc32_dev(d, out, adler=1, crc=0, length=n, offset=phase)
+        got = [v & 0xffffffff for v in out.tolist()]
+        # property check, independent of the oracle: 37 ragged blocks, combine on device
+        edges = np.linspace(0, n, 38).astype(np.int64)
+        edges[1:-1] += np.arange(1, 37) * 7
+        a_chk = torch.zeros(37, dtype=torch.int32, device="cuda")
+        c_chk = torch.zeros(37, dtype=torch.int32, device="cuda")
+        tmp = torch.zeros(2, dtype=torch.int32, device="cuda")
+        for i in range(37):
+            zr.adler32_crc32_dev(d, tmp, length=int(edges[i + 1] - edges[i]), offset=phase + int(edges[i]))
+            a_chk[i] = tmp[0]
+            c_chk[i] = tmp[1]
+        d_lens = torch.from_numpy(np.diff(edges)).cuda()
+        zr.adler32_combine_dev(a_chk, d_lens, tmp)
+        ca = tmp[0].item() & 0xffffffff
+        zr.crc32_combine_dev(c_chk, d_lens, tmp)
+        cc = tmp[0].item() & 0xffffffff
+        assert [ca, cc] == got
+        if phase == 0:
+            host = d.cpu().numpy()
+            assert got[0] == oracle.oracle_adler32(1, host.ctypes.data, n)
+            assert got[1] == oracle.oracle_crc32_braid(0, host.ctypes.data, n)
+            del host

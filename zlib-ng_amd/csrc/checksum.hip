@@ -1,0 +1,414 @@
+// checksum.hip -- Adler-32 / CRC-32 on gfx950: block-parallel streaming kernels with
+// on-device combine.
+//
+// Replaces, behind the functable boundary (functable.h:26-42):
+//   adler32            arch/generic/adler32_c.c:11-54
+//   crc32              arch/generic/crc32_braid_c.c:62-216
+//   adler32_fold_copy  arch/generic/adler32_fold_c.c:11-15
+//   crc32_fold_copy    arch/generic/crc32_fold_c.c:15-18
+// and evaluates the combine identities of adler32.c:32-54 / crc32_braid_comb.c:16-18
+// on the device.
+//
+// Data layout.  The message [buf, buf+n) is cut on 16-byte address granules:
+//   a0        = buf rounded down to 16        (first granule; its bytes below buf are masked to 0)
+//   tail_base = (buf+n) rounded down to 16    (the <16 trailing bytes are folded in by the finalize kernel)
+//   body      = [a0, tail_base), consumed in UNITS of 16 KiB = 1024 lanes x one dwordx4 each,
+//               units right-aligned to tail_base (a partial unit can only be the FIRST one, and
+//               missing leading pieces behave as leading zero bytes, which change neither checksum).
+// Workgroup g owns a contiguous run of units; per step its 1024 lanes read one fully
+// coalesced 16 KiB row.  Each lane therefore sees a strided sub-stream (stride 16 KiB):
+//   CRC:   four braids per lane (the four dwords of its piece).  One step is the braid step of
+//          crc32_braid_c.c:121-176 with the stride n*w = 16 KiB:  s <- s * x^(8*16384) ^ word,
+//          done with four byte-indexed tables held in LDS, each replicated over the 32 banks
+//          (entry e of lane l at bank l%32) so that every ds_read_b32 is conflict-free.
+//   Adler: lane-local byte sum A (v_sad_u8) and in-piece weighted sum (v_dot4_u32_u8); positions
+//          are applied in closed form, B = sum (n - pos) * byte, so blocks combine by plain addition
+//          (the linear form of adler32_combine_).
+// Each workgroup leaves one Partial; the finalize kernel applies x^(8*bytes_after) (CRC) and sums
+// (Adler), folds the tail bytes and the seed, and writes the checksum(s) to device memory.
+#include "context.h"
+
+namespace zr {
+
+// first `k` bytes (k in 0..15) of a piece -> 0
+__device__ __forceinline__ uint4 mask_low_bytes(uint4 v, int k) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int kk = k - 4 * i;                      // bytes of dword i to clear
+        if (kk >= 4) w[i] = 0;
+        else if (kk > 0) w[i] &= 0xffffffffu << (8 * kk);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One braid step for one dword: s * x^(8*stride) ^ w, via the bank-replicated LDS tables.
+// lut layout: dword index ((k*256 + e) << 5) + (lane & 31).
+__device__ __forceinline__ uint32_t braid_step(const uint32_t *lut, uint32_t rep, uint32_t s, uint32_t w) {
+    uint32_t r0 = lut[(((s)       & 0xffu) << 5) + rep];
+    uint32_t r1 = lut[(1u << 13) + (((s >> 8)  & 0xffu) << 5) + rep];
+    uint32_t r2 = lut[(2u << 13) + (((s >> 16) & 0xffu) << 5) + rep];
+    uint32_t r3 = lut[(3u << 13) + (((s >> 24)       ) << 5) + rep];
+    return r0 ^ r1 ^ r2 ^ r3 ^ w;
+}
+
+struct StreamArgs {
+    const uint8_t *a0;        // 16-byte aligned
+    uint8_t       *dst0;      // COPY: destination of byte a0[0] (same 16-byte phase as a0), else unused
+    long long      n;         // message bytes
+    long long      body;      // tail_base - a0 (multiple of 16, >= 0)
+    long long      nunits;    // ceil(body / kUnitBytes)
+    int            head;      // buf - a0, 0..15
+    int            tail;      // bytes of the message living in the granule at tail_base
+};
+
+// DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
+template <bool DO_ADLER, bool DO_CRC, bool COPY>
+__global__ __launch_bounds__(kWgThreads)
+void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
+    __shared__ uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
+    __shared__ uint32_t red[3][kWgThreads / 64];
+
+    const int t = threadIdx.x;
+    const uint32_t rep = t & 31;
+
+    if constexpr (DO_CRC) {
+        // 32768 dwords, lane-consecutive LDS writes; the 32 replicas of one entry are 32 adjacent dwords
+        const uint32_t *src = &tabs->stride_tab[0][0];
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            int idx = i * kWgThreads + t;
+            lut[idx] = src[idx >> 5];
+        }
+        __syncthreads();
+    }
+
+    // contiguous run of units for this workgroup
+    const long long G = gridDim.x, g = blockIdx.x;
+    const long long q = args.nunits / G, r = args.nunits % G;
+    const long long u_lo = g * q + (g < r ? g : r);
+    const long long u_hi = u_lo + q + (g < r ? 1 : 0);
+
+    // byte offset (relative to a0) of this lane's piece in unit u:  body - (nunits-u)*U + 16t
+    long long off = args.body - (args.nunits - u_lo) * (long long)kUnitBytes + (long long)t * kPieceBytes;
+
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;             // CRC braids
+    uint32_t S1 = 0, SR = 0, SW = 0;                     // Adler: byte sum, prefix-of-sums, in-piece weights
+    unsigned long long accA = 0, accB = 0;               // Adler, reduced mod BASE between batches
+    int batch = 0;
+
+    auto fold_adler = [&](long long off_last) {
+        // B over the batch = sum_k (n - o_k - 16) * A_k + W_k, o_k = piece offset relative to buf.
+        // With pieces one unit apart:  (n - o_last - 16) * S1 + U * SR + SW  (all terms >= 0).
+        unsigned long long lead = (unsigned long long)(args.n - (off_last - args.head) - kPieceBytes);
+        unsigned long long v = (lead % kAdlerBase) * S1 + (unsigned long long)kUnitBytes * SR + SW;
+        accB = (accB + v) % kAdlerBase;
+        accA = (accA + S1) % kAdlerBase;
+        S1 = SR = SW = 0;
+        batch = 0;
+    };
+
+    auto consume = [&](uint4 v) {
+        if constexpr (DO_CRC) {
+            s0 = braid_step(lut, rep, s0, v.x);
+            s1 = braid_step(lut, rep, s1, v.y);
+            s2 = braid_step(lut, rep, s2, v.z);
+            s3 = braid_step(lut, rep, s3, v.w);
+        }
+        if constexpr (DO_ADLER) {
+            uint32_t a = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
+            a = __builtin_amdgcn_sad_u8(v.y, 0u, a);
+            a = __builtin_amdgcn_sad_u8(v.z, 0u, a);
+            a = __builtin_amdgcn_sad_u8(v.w, 0u, a);
+            uint32_t w = __builtin_amdgcn_udot4(v.x, 0x0D0E0F10u, 0u, false);   // weights 16,15,14,13
+            w = __builtin_amdgcn_udot4(v.y, 0x090A0B0Cu, w, false);            // 12..9
+            w = __builtin_amdgcn_udot4(v.z, 0x05060708u, w, false);            // 8..5
+            w = __builtin_amdgcn_udot4(v.w, 0x01020304u, w, false);            // 4..1
+            SR += S1;
+            S1 += a;
+            SW += w;
+        }
+    };
+
+    long long u = u_lo;
+    // first unit of the whole message may be partial (pieces below a0 do not exist) and holds the head mask
+    if (u < u_hi && u == 0) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off >= 0) {
+            v = *reinterpret_cast<const uint4 *>(args.a0 + off);
+            if (off == 0 && args.head) v = mask_low_bytes(v, args.head);
+            if constexpr (COPY) {
+                if (off == 0 && args.head) {
+                    for (int j = args.head; j < 16; ++j) args.dst0[j] = args.a0[j];
+                } else {
+                    *reinterpret_cast<uint4 *>(args.dst0 + off) = v;
+                }
+            }
+        }
+        consume(v);
+        if constexpr (DO_ADLER) { batch = 1; }
+        off += kUnitBytes;
+        ++u;
+    }
+
+    constexpr int UNROLL = 4;
+    constexpr int BATCH_MAX = 240;     // u32 bounds: SR <= 4080 * 240*239/2 < 2^27
+    for (; u + UNROLL <= u_hi; u += UNROLL) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j)
+            v[j] = *reinterpret_cast<const uint4 *>(args.a0 + off + (long long)j * kUnitBytes);
+        if constexpr (COPY) {
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j)
+                *reinterpret_cast<uint4 *>(args.dst0 + off + (long long)j * kUnitBytes) = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) consume(v[j]);
+        off += (long long)UNROLL * kUnitBytes;
+        if constexpr (DO_ADLER) {
+            batch += UNROLL;
+            if (batch >= BATCH_MAX) fold_adler(off - kUnitBytes);
+        }
+    }
+    for (; u < u_hi; ++u) {
+        uint4 v = *reinterpret_cast<const uint4 *>(args.a0 + off);
+        if constexpr (COPY) *reinterpret_cast<uint4 *>(args.dst0 + off) = v;
+        consume(v);
+        off += kUnitBytes;
+        if constexpr (DO_ADLER) ++batch;
+    }
+    if constexpr (DO_ADLER) {
+        if (batch) fold_adler(off - kUnitBytes);
+    }
+
+    // ---- workgroup reduction ------------------------------------------------
+    uint32_t pc = 0;
+    if constexpr (DO_CRC) {
+        if (u_hi > u_lo) {
+            const uint32_t *lw = tabs->lane_weight[t];
+            pc = mulmod(s0, lw[0]) ^ mulmod(s1, lw[1]) ^ mulmod(s2, lw[2]) ^ mulmod(s3, lw[3]);
+        }
+    }
+    uint32_t pa = (uint32_t)accA, pb = (uint32_t)accB;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        if constexpr (DO_CRC) pc ^= __shfl_xor(pc, m, 64);
+        if constexpr (DO_ADLER) {
+            pa += __shfl_xor(pa, m, 64);
+            pb += __shfl_xor(pb, m, 64);
+        }
+    }
+    const int wave = t >> 6;
+    if ((t & 63) == 0) {
+        red[0][wave] = pc;
+        red[1][wave] = pa;     // <= 64 * 65520
+        red[2][wave] = pb;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t c = 0;
+        unsigned long long a = 0, b = 0;
+        for (int w = 0; w < kWgThreads / 64; ++w) {
+            c ^= red[0][w];
+            a += red[1][w];
+            b += red[2][w];
+        }
+        Partial p;
+        p.crc = c;
+        p.a = (uint32_t)(a % kAdlerBase);
+        p.b = (uint32_t)(b % kAdlerBase);
+        p.pad = 0;
+        partials[g] = p;
+    }
+}
+
+struct FinalArgs {
+    const uint8_t *tail_base;   // granule holding the trailing bytes
+    uint8_t       *tail_dst;    // COPY: where those bytes go (else nullptr)
+    long long      n;
+    long long      nunits;
+    int            tail_lo;     // valid bytes of that granule: [tail_lo, tail_hi)
+    int            tail_hi;
+    int            groups;
+    uint32_t       adler_seed;
+    uint32_t       crc_seed;
+    int            do_adler, do_crc;
+};
+
+__global__ __launch_bounds__(256)
+void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const Partial *__restrict__ partials,
+                     uint32_t *__restrict__ out_adler, uint32_t *__restrict__ out_crc) {
+    __shared__ uint32_t red[3][4];
+    const int t = threadIdx.x;
+    const long long G = fa.groups;
+    const long long q = fa.nunits / G, r = fa.nunits % G;
+    const int ntail = fa.tail_hi - fa.tail_lo;
+
+    uint32_t c = 0;
+    unsigned long long a = 0, b = 0;
+    for (long long g = t; g < G; g += blockDim.x) {
+        Partial p = partials[g];
+        long long u_hi = g * q + (g < r ? g : r) + q + (g < r ? 1 : 0);
+        if (fa.do_crc && p.crc) {
+            unsigned long long after = (unsigned long long)(fa.nunits - u_hi) * kUnitBytes + (unsigned long long)ntail;
+            c ^= mulmod(p.crc, xpow_bytes(tabs->pow_tab, after));
+        }
+        a += p.a;
+        b += p.b;
+    }
+    // trailing (< 16) bytes: one lane each
+    if (t < ntail) {
+        uint32_t byte = fa.tail_base[fa.tail_lo + t];
+        if (fa.tail_dst) fa.tail_dst[fa.tail_lo + t] = (uint8_t)byte;
+        int after = ntail - 1 - t;                  // message bytes behind this one
+        if (fa.do_crc) c ^= mulmod(tabs->byte_tab[byte], tabs->pow_tab[after]);
+        a += byte;
+        b += (unsigned long long)byte * (unsigned)(after + 1);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        c ^= __shfl_xor(c, m, 64);
+        a += __shfl_xor(a, m, 64);
+        b += __shfl_xor(b, m, 64);
+    }
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = c;
+        red[1][t >> 6] = (uint32_t)(a % kAdlerBase);
+        red[2][t >> 6] = (uint32_t)(b % kAdlerBase);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t cc = red[0][0] ^ red[0][1] ^ red[0][2] ^ red[0][3];
+        unsigned long long A = (unsigned long long)red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        unsigned long long B = (unsigned long long)red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (fa.do_adler) {
+            // seed halves are masked, not reduced (adler32_c.c:16-17); s1' = s1 + A, s2' = s2 + n*s1 + B
+            unsigned long long s1 = fa.adler_seed & 0xffffu, s2 = (fa.adler_seed >> 16) & 0xffffu;
+            unsigned long long n_mod = (unsigned long long)fa.n % kAdlerBase;
+            unsigned long long r1 = (s1 + A) % kAdlerBase;
+            unsigned long long r2 = (s2 + n_mod * s1 + B) % kAdlerBase;
+            *out_adler = (uint32_t)(r1 | (r2 << 16));
+        }
+        if (fa.do_crc) {
+            // register started at ~seed: its image after n bytes is ~seed * x^(8n)
+            uint32_t init = mulmod(~fa.crc_seed, xpow_bytes(tabs->pow_tab, (unsigned long long)fa.n));
+            *out_crc = ~(cc ^ init);
+        }
+    }
+}
+
+// ---- host launcher ----------------------------------------------------------
+static int pick_groups(const Context *c, long long nunits) {
+    long long g = c->cus;                 // one 1024-thread workgroup per CU
+    if (g > kMaxGroups) g = kMaxGroups;
+    if (nunits < g) g = nunits > 0 ? nunits : 1;
+    return (int)g;
+}
+
+int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const void *d_buf, void *d_dst,
+                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream) {
+    Context *c = ctx();
+    if (!c) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if ((!d_buf && len) || (do_adler && !d_out_adler) || (do_crc && !d_out_crc)) {
+        set_error("null device pointer");
+        return ZNG_ROCM_EINVAL;
+    }
+    if (len >> 34) {
+        set_error("length above 16 GiB per call is not supported");
+        return ZNG_ROCM_EINVAL;
+    }
+    Workspace *ws = workspace_for(stream);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+
+    const uintptr_t p = (uintptr_t)d_buf;
+    const uintptr_t a0 = p & ~(uintptr_t)15;
+    const uintptr_t tail_base = (p + len) & ~(uintptr_t)15;
+    const bool copy = d_dst != nullptr;
+    if (copy && (((uintptr_t)d_dst ^ p) & 15)) {
+        set_error("fold_copy needs src and dst with the same address mod 16");
+        return ZNG_ROCM_EINVAL;
+    }
+
+    StreamArgs sa;
+    sa.a0 = (const uint8_t *)a0;
+    sa.dst0 = copy ? (uint8_t *)d_dst - (p - a0) : nullptr;
+    sa.n = (long long)len;
+    sa.body = (long long)(tail_base - a0);
+    sa.nunits = (sa.body + kUnitBytes - 1) / kUnitBytes;
+    sa.head = (int)(p - a0);
+    sa.tail = (int)((p + len) - tail_base);
+
+    FinalArgs fa;
+    fa.tail_base = (const uint8_t *)tail_base;
+    fa.tail_dst = copy ? (uint8_t *)d_dst + (tail_base - p) : nullptr;   // may point before d_dst when body == 0
+    fa.n = sa.n;
+    fa.nunits = sa.nunits;
+    fa.tail_lo = sa.body == 0 ? sa.head : 0;
+    fa.tail_hi = sa.tail;
+    if (len == 0) fa.tail_lo = fa.tail_hi = 0;
+    fa.adler_seed = adler;
+    fa.crc_seed = crc;
+    fa.do_adler = do_adler;
+    fa.do_crc = do_crc;
+
+    const int groups = pick_groups(c, sa.nunits);
+    fa.groups = groups;
+    if (sa.nunits > 0) {
+        dim3 grid(groups), block(kWgThreads);
+        trace_mark(stream, true);
+#define ZR_LAUNCH(A, C, K) \
+        hipLaunchKernelGGL((stream_kernel<A, C, K>), grid, block, 0, stream, sa, c->tables, ws->partials)
+        if (copy) {
+            if (do_adler && do_crc) ZR_LAUNCH(true, true, true);
+            else if (do_adler) ZR_LAUNCH(true, false, true);
+            else ZR_LAUNCH(false, true, true);
+        } else {
+            if (do_adler && do_crc) ZR_LAUNCH(true, true, false);
+            else if (do_adler) ZR_LAUNCH(true, false, false);
+            else ZR_LAUNCH(false, true, false);
+        }
+#undef ZR_LAUNCH
+        trace_mark(stream, false);
+        ZR_HIP(hipGetLastError());
+    } else {
+        ZR_HIP(hipMemsetAsync(ws->partials, 0, sizeof(Partial) * groups, stream));
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, fa, c->tables, ws->partials,
+                       d_out_adler, d_out_crc);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+int zng_rocm_adler32_dev(uint32_t adler, const void *d_buf, size_t len, uint32_t *d_out, void *stream) {
+    return launch_checksum(true, false, adler, 0, d_buf, nullptr, len, d_out, nullptr, (hipStream_t)stream);
+}
+
+int zng_rocm_crc32_dev(uint32_t crc, const void *d_buf, size_t len, uint32_t *d_out, void *stream) {
+    return launch_checksum(false, true, 0, crc, d_buf, nullptr, len, nullptr, d_out, (hipStream_t)stream);
+}
+
+int zng_rocm_adler32_crc32_dev(uint32_t adler, uint32_t crc, const void *d_buf, size_t len, uint32_t *d_out2,
+                               void *stream) {
+    if (!d_out2) return ZNG_ROCM_EINVAL;
+    return launch_checksum(true, true, adler, crc, d_buf, nullptr, len, d_out2, d_out2 + 1, (hipStream_t)stream);
+}
+
+int zng_rocm_fold_copy_dev(int which, uint32_t adler, uint32_t crc, void *d_dst, const void *d_src, size_t len,
+                           uint32_t *d_out2, void *stream) {
+    if (which < 1 || which > 3 || !d_out2 || (!d_dst && len)) return ZNG_ROCM_EINVAL;
+    if (len == 0) d_dst = nullptr;
+    return launch_checksum((which & 1) != 0, (which & 2) != 0, adler, crc, d_src, d_dst, len, d_out2, d_out2 + 1,
+                           (hipStream_t)stream);
+}
+
+}  // extern "C"

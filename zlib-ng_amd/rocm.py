@@ -1,0 +1,258 @@
+"""ctypes binding of include/zng_rocm.h (the C-ABI drop-in boundary)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libzng_rocm.so")
+_lib = None
+
+
+class ZngRocmError(RuntimeError):
+    pass
+
+
+class Crc32FoldState(C.Structure):
+    """struct crc32_fold_s (crc32.h:8-14)"""
+    _fields_ = [("fold", C.c_uint8 * 64), ("value", C.c_uint32)]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(cmd, stdout=out)
+    return _LIB_PATH
+
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "zng_rocm_init": (C.c_int, [C.c_int]),
+    "zng_rocm_available": (C.c_int, []),
+    "zng_rocm_device_count": (C.c_int, []),
+    "zng_rocm_last_error": (C.c_char_p, []),
+    "zng_rocm_device_info": (C.c_int, [C.POINTER(C.c_int32)]),
+    "zng_rocm_shutdown": (C.c_int, []),
+    "zng_rocm_adler32": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
+    "zng_rocm_adler32_fold_copy": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zng_rocm_crc32": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
+    "zng_rocm_crc32_fold_reset": (C.c_uint32, [C.POINTER(Crc32FoldState)]),
+    "zng_rocm_crc32_fold": (None, [C.POINTER(Crc32FoldState), C.c_void_p, C.c_size_t, C.c_uint32]),
+    "zng_rocm_crc32_fold_copy": (None, [C.POINTER(Crc32FoldState), C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zng_rocm_crc32_fold_final": (C.c_uint32, [C.POINTER(Crc32FoldState)]),
+    "zng_rocm_adler32_dev": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_crc32_dev": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_adler32_crc32_dev": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_fold_copy_dev": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p]),
+    "zng_rocm_adler32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_crc32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_trace_begin": (C.c_int, [C.c_int]),
+    "zng_rocm_trace_end": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
+    "zng_rocm_adler32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
+    "zng_rocm_crc32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
+    "zng_rocm_crc32_combine_gen": (C.c_uint32, [C.c_int64]),
+    "zng_rocm_crc32_combine_op": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+}
+
+
+def exported_names():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ZngRocmError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % _LIB_PATH)
+        handle = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)          # AttributeError = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ZngRocmError("%s failed (%d): %s" % (what, rc, lib().zng_rocm_last_error().decode()))
+
+
+def device_count():
+    return lib().zng_rocm_device_count()
+
+
+def available():
+    return bool(lib().zng_rocm_available())
+
+
+def init(device=-1):
+    _check(lib().zng_rocm_init(device), "zng_rocm_init")
+
+
+def _need_init():
+    if not lib().zng_rocm_available():
+        init(-1)
+
+
+# ---- host-pointer slots, reference names ---------------------------------
+def _host_ptr(data):
+    """(keepalive, address, nbytes) for bytes / bytearray / numpy / None"""
+    if data is None:
+        return None, None, 0
+    if isinstance(data, (bytes, bytearray, memoryview)):
+        raw = bytes(data)
+        keep = C.create_string_buffer(raw, max(len(raw), 1))
+        return keep, C.addressof(keep), len(raw)
+    import numpy as np
+    arr = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    return arr, arr.ctypes.data, arr.size
+
+
+def adler32_z(adler, buf, length=None):
+    """zng_adler32_z (adler32.c:15-17) through the `adler32` slot."""
+    _need_init()
+    keep, ptr, n = _host_ptr(buf)
+    n = n if length is None else length
+    return lib().zng_rocm_adler32(adler & 0xffffffff, ptr, n)
+
+
+def crc32_z(crc, buf, length=None):
+    """zng_crc32_z (crc32.c:27-31) through the `crc32` slot (NULL -> 0)."""
+    _need_init()
+    keep, ptr, n = _host_ptr(buf)
+    n = n if length is None else length
+    return lib().zng_rocm_crc32(crc & 0xffffffff, ptr, n)
+
+
+def adler32(buf, adler=1):
+    return adler32_z(adler, buf)
+
+
+def crc32(buf, crc=0):
+    return crc32_z(crc, buf)
+
+
+def adler32_fold_copy(adler, buf):
+    """slot adler32_fold_copy: returns (checksum, copied bytes)"""
+    _need_init()
+    keep, ptr, n = _host_ptr(buf)
+    dst = C.create_string_buffer(max(n, 1))
+    val = lib().zng_rocm_adler32_fold_copy(adler & 0xffffffff, C.addressof(dst), ptr, n)
+    return val, dst.raw[:n]
+
+
+class Crc32Fold:
+    """crc32_fold_reset / crc32_fold / crc32_fold_copy / crc32_fold_final"""
+
+    def __init__(self):
+        _need_init()
+        self.state = Crc32FoldState()
+        self.reset()
+
+    def reset(self):
+        return lib().zng_rocm_crc32_fold_reset(C.byref(self.state))
+
+    def fold(self, buf, init_crc=0):
+        keep, ptr, n = _host_ptr(buf)
+        lib().zng_rocm_crc32_fold(C.byref(self.state), ptr, n, init_crc)
+
+    def fold_copy(self, buf):
+        keep, ptr, n = _host_ptr(buf)
+        dst = C.create_string_buffer(max(n, 1))
+        lib().zng_rocm_crc32_fold_copy(C.byref(self.state), C.addressof(dst), ptr, n)
+        return dst.raw[:n]
+
+    def final(self):
+        return lib().zng_rocm_crc32_fold_final(C.byref(self.state))
+
+
+def adler32_combine(adler1, adler2, len2):
+    return lib().zng_rocm_adler32_combine(adler1, adler2, len2)
+
+
+def crc32_combine(crc1, crc2, len2):
+    return lib().zng_rocm_crc32_combine(crc1, crc2, len2)
+
+
+def crc32_combine_gen(len2):
+    return lib().zng_rocm_crc32_combine_gen(len2)
+
+
+def crc32_combine_op(crc1, crc2, op):
+    return lib().zng_rocm_crc32_combine_op(crc1, crc2, op)
+
+
+# ---- device-resident entry points (torch tensors carry the memory) --------
+def _stream_ptr(stream):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def _dev_ptr(t, offset=0):
+    return C.c_void_p(t.data_ptr() + offset)
+
+
+def adler32_dev(buf, out, adler=1, length=None, offset=0, stream=None):
+    """buf: uint8 CUDA tensor; out: uint32/int32 CUDA tensor (>= 1 element). Async on `stream`."""
+    _need_init()
+    n = buf.numel() - offset if length is None else length
+    _check(lib().zng_rocm_adler32_dev(adler & 0xffffffff, _dev_ptr(buf, offset), n, _dev_ptr(out),
+                                      _stream_ptr(stream)), "zng_rocm_adler32_dev")
+
+
+def crc32_dev(buf, out, crc=0, length=None, offset=0, stream=None):
+    _need_init()
+    n = buf.numel() - offset if length is None else length
+    _check(lib().zng_rocm_crc32_dev(crc & 0xffffffff, _dev_ptr(buf, offset), n, _dev_ptr(out),
+                                    _stream_ptr(stream)), "zng_rocm_crc32_dev")
+
+
+def adler32_crc32_dev(buf, out2, adler=1, crc=0, length=None, offset=0, stream=None):
+    _need_init()
+    n = buf.numel() - offset if length is None else length
+    _check(lib().zng_rocm_adler32_crc32_dev(adler & 0xffffffff, crc & 0xffffffff, _dev_ptr(buf, offset), n,
+                                            _dev_ptr(out2), _stream_ptr(stream)), "zng_rocm_adler32_crc32_dev")
+
+
+def fold_copy_dev(which, dst, src, out2, adler=1, crc=0, length=None, src_offset=0, dst_offset=0, stream=None):
+    _need_init()
+    n = src.numel() - src_offset if length is None else length
+    _check(lib().zng_rocm_fold_copy_dev(which, adler & 0xffffffff, crc & 0xffffffff, _dev_ptr(dst, dst_offset),
+                                        _dev_ptr(src, src_offset), n, _dev_ptr(out2), _stream_ptr(stream)),
+           "zng_rocm_fold_copy_dev")
+
+
+def adler32_combine_dev(checks, lens, out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_adler32_combine_dev(_dev_ptr(checks), _dev_ptr(lens), checks.numel(), _dev_ptr(out),
+                                              _stream_ptr(stream)), "zng_rocm_adler32_combine_dev")
+
+
+def crc32_combine_dev(checks, lens, out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_crc32_combine_dev(_dev_ptr(checks), _dev_ptr(lens), checks.numel(), _dev_ptr(out),
+                                            _stream_ptr(stream)), "zng_rocm_crc32_combine_dev")
+
+
+def trace_begin(max_launches):
+    _need_init()
+    _check(lib().zng_rocm_trace_begin(max_launches), "zng_rocm_trace_begin")
+
+
+def trace_end(cap=4096):
+    """per-launch durations (ms) of the dominant kernel since trace_begin"""
+    buf = (C.c_float * cap)()
+    n = lib().zng_rocm_trace_end(buf, cap)
+    if n < 0:
+        _check(n, "zng_rocm_trace_end")
+    return [buf[i] for i in range(n)]
