@@ -72,6 +72,10 @@ def lib():
             raise ZngRocmError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % _LIB_PATH)
+        # torch ships its own libamdhip64.so.7 (+ HSA runtime); import it FIRST so this library
+        # binds to the HIP runtime already in the process instead of loading a second one
+        # from /opt/rocm (two HIP runtimes in one process cannot both own the device).
+        import torch  # noqa: F401
         handle = C.CDLL(_LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)          # AttributeError = header and library out of sync
