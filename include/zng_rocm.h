@@ -107,6 +107,58 @@ uint32_t zng_rocm_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
 uint32_t zng_rocm_crc32_combine_gen(int64_t len2);
 uint32_t zng_rocm_crc32_combine_op(uint32_t crc1, uint32_t crc2, uint32_t op);
 
+/* ---- deflate-side primitives on device-resident stream state -------------
+ * The window/prev/head slabs of `deflate_state` (deflate.h:164-244, layout
+ * deflate.c:202-264) live in HBM; one `zng_rocm_deflate_view` per stream is the
+ * subset of fields the functable kernels read.  A
+ * stream-level offload (DEFLATE_HOOK) marshals these from its deflate_state.
+ * Every call below works on an ARRAY of views in device memory: one wavefront
+ * per stream, all streams of the batch in one launch.  Field meaning is the
+ * reference's. */
+typedef struct zng_rocm_deflate_view {
+    uint8_t  *window;            /* device; 2*w_size bytes + >= 258+8 readable padding (deflate.c:1341-1372) */
+    uint16_t *prev;              /* device; w_size Pos entries */
+    uint16_t *head;              /* device; 65536 Pos entries (HASH_SIZE, deflate.h:81-85) */
+    uint32_t  w_size, w_mask;
+    uint32_t  lookahead, strstart, match_start, prev_length;
+    uint32_t  max_chain_length, good_match;
+    int32_t   nice_match, level;
+} zng_rocm_deflate_view;
+
+/* slot `slide_hash` (arch/generic/slide_hash_c.c:15-52) for nstreams states: every head[] and
+ * prev[] entry m becomes m >= w_size ? m - w_size : 0. */
+int zng_rocm_slide_hash_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, void *stream);
+/* slot `compare256` (arch/generic/compare256_c.c:12-47): d_len[i] = first differing byte of
+ * d_base + d_off0[i] and d_base + d_off1[i], capped at 256 (both must have 256 readable bytes). */
+int zng_rocm_compare256_dev(const uint8_t *d_base, const uint64_t *d_off0, const uint64_t *d_off1, size_t npairs,
+                            uint32_t *d_len, void *stream);
+/* `update_hash` (insert_string.c:11-13, insert_string_tpl.h:48-51) over an array of 4-byte values */
+int zng_rocm_update_hash_dev(const uint32_t *d_val, size_t n, uint32_t *d_hash, void *stream);
+/* `quick_insert_string` (insert_string_tpl.h:58-75): stream i inserts position d_str[i]; d_head_out[i]
+ * receives the previous chain head. */
+int zng_rocm_quick_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                                     uint16_t *d_head_out, void *stream);
+/* `insert_string` (insert_string_tpl.h:85-104): stream i inserts d_count[i] consecutive positions from d_str[i],
+ * in order. */
+int zng_rocm_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                               const uint32_t *d_count, void *stream);
+/* slot `longest_match` (match_tpl.h:26-280, non-SLOW): for stream i walks the chain from d_cur_match[i];
+ * d_len_out[i] = returned length, d_match_start_out[i] = s->match_start afterwards (unchanged if no
+ * longer match was found). */
+int zng_rocm_longest_match_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint16_t *d_cur_match,
+                               uint32_t *d_len_out, uint32_t *d_match_start_out, void *stream);
+
+/* ---- inflate-side copy primitive ------------------------------------------
+ * slot `chunkmemset_safe` (chunkset_tpl.h:229-261) as a batch of INDEPENDENT copies inside one device
+ * buffer: copy i writes out = d_base + d_out_off[i], reads from = d_base + d_from_off[i], with the
+ * reference's contract on [out, out + min(len,left)): forward byte-serial copy (a distance shorter than
+ * the length replicates the pattern; `from` ahead of `out` behaves like memmove).  Nothing outside that
+ * range is written.  Copies of one batch must not depend on each other. */
+int zng_rocm_chunkmemset_safe_dev(uint8_t *d_base, const uint64_t *d_out_off, const uint64_t *d_from_off,
+                                  const uint32_t *d_len, const uint32_t *d_left, size_t ncopies, void *stream);
+/* slot `chunksize` (chunkset_tpl.h:9-11): store granule of the device copy kernels (bytes). */
+uint32_t zng_rocm_chunksize(void);
+
 /* ---- measurement hooks --------------------------------------------------
  * Between trace_begin and trace_end every launch of the DOMINANT kernel of a
  * *_dev entry point (the streaming kernel, not its finalize step) is bracketed

@@ -1,0 +1,133 @@
+// deflate_dev.h -- wave64 device building blocks for zlib-ng's deflate-side functable
+// primitives.  One wavefront works on one stream / one query; scalars (positions, lengths,
+// chain state) are wave-uniform, the 64 lanes are used for the data-parallel parts
+// (256-byte compares = 64 lanes x 4 bytes, 64 consecutive hash insertions).
+//
+// Reference semantics restated here (zlib-ng 2.2.2):
+//   compare256        arch/generic/compare256_c.c:12-47
+//   update_hash etc.  insert_string.c:11-19, insert_string_tpl.h:48-104
+//   longest_match     match_tpl.h:26-280 (non-SLOW instantiation)
+//   slide_hash        arch/generic/slide_hash_c.c:15-52
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/zng_rocm.h"
+
+namespace zr {
+
+constexpr uint32_t kHashSize = 65536u;        // deflate.h:81-85
+constexpr uint32_t kStdMinMatch = 3, kStdMaxMatch = 258;
+constexpr uint32_t kMinLookahead = kStdMaxMatch + kStdMinMatch + 1;   // deflate.h:405
+
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+__device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
+    return *reinterpret_cast<const u32_unaligned *>(p);
+}
+
+// insert_string.c:11-13 + insert_string_tpl.h:48-51 (HASH_SLIDE 16, HASH_MASK 0xffff)
+__device__ __forceinline__ uint32_t hash_calc(uint32_t val) {
+    return ((val * 2654435761u) >> 16) & (kHashSize - 1u);
+}
+
+// compare256: first differing byte index of two 256-byte strings (256 if equal).
+// All 64 lanes participate; result is wave-uniform.
+__device__ __forceinline__ uint32_t compare256_wave(const uint8_t *a, const uint8_t *b, int lane) {
+    const uint32_t x = load_u32(a + 4 * lane);
+    const uint32_t y = load_u32(b + 4 * lane);
+    const unsigned long long diff = __ballot(x != y);
+    if (diff == 0) return 256u;
+    const int first = __ffsll((long long)diff) - 1;
+    const uint32_t d = (uint32_t)__shfl((int)(x ^ y), first, 64);
+    return (uint32_t)first * 4u + ((uint32_t)(__ffs((int)d) - 1) >> 3);
+}
+
+// insert_string_tpl.h:85-104 for `count` consecutive positions, 64 per pass.
+// Sequential semantics are kept exactly: a position whose hash equals that of an earlier
+// position of the same pass sees that position as the chain head.
+__device__ __forceinline__ void insert_string_wave(const uint8_t *window, uint16_t *head, uint16_t *prev,
+                                                   uint32_t w_mask, uint32_t str, uint32_t count, int lane) {
+    for (uint32_t base = 0; base < count; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool live = i < count;
+        const uint32_t pos = str + i;
+        const uint16_t idx = (uint16_t)pos;                   // `Pos idx` wraps at 16 bits
+        uint32_t h = live ? hash_calc(load_u32(window + pos)) : 0xffffffffu;
+        // nearest earlier lane with the same hash, and whether a later one exists
+        int before = -1;
+        bool later = false;
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t hj = (uint32_t)__shfl((int)h, j, 64);
+            const bool same = live && hj == h;
+            if (same && j < lane) before = j;
+            if (same && j > lane) later = true;
+        }
+        const uint16_t idx_before = (uint16_t)__shfl((int)idx, before < 0 ? 0 : before, 64);
+        if (live) {
+            const uint16_t old = before >= 0 ? idx_before : head[h];
+            if (old != idx) {
+                prev[idx & w_mask] = old;
+                if (!later) head[h] = idx;
+            }
+        }
+        // a later pass must see this pass's stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
+struct MatchParams {           // the deflate_state fields match_tpl.h reads (deflate.h:164-244)
+    const uint8_t  *window;
+    const uint16_t *prev;
+    uint32_t w_size, w_mask, strstart, lookahead, prev_length, max_chain_length, good_match, nice_match;
+    int32_t  level;
+};
+
+// match_tpl.h:26-280 (non-SLOW).  Returns the match length; *match_start is written when a
+// longer match is found (match_tpl.h:178-179).  Wave-uniform control flow; the byte-pair probes
+// are the OPTIMAL_CMP < 32 form (:167-173) -- for level >= 5 every form accepts the same
+// candidates (the probes only skip candidates that cannot beat best_len); for level < 5 the
+// early exit (:261-266) is evaluated with these probes, i.e. it follows longest_match_c.
+__device__ __forceinline__ uint32_t longest_match_wave(const MatchParams &s, uint32_t cur_match,
+                                                       uint32_t *match_start, int lane) {
+    const uint8_t *window = s.window;
+    const uint8_t *scan = window + s.strstart;
+    uint32_t best_len = s.prev_length ? s.prev_length : kStdMinMatch - 1;
+    uint32_t offset = best_len - 1;
+    uint32_t chain_length = s.max_chain_length;
+    if (best_len >= s.good_match) chain_length >>= 2;
+    const uint32_t max_dist = s.w_size - kMinLookahead;
+    const uint32_t limit = s.strstart > max_dist ? (uint16_t)(s.strstart - max_dist) : 0;
+    const bool early_exit = s.level < 5;
+    const uint8_t sc0 = scan[0], sc1 = scan[1];
+    uint8_t end0 = scan[offset], end1 = scan[offset + 1];
+
+    for (;;) {
+        if (cur_match >= s.strstart) break;
+        // skip candidates that cannot improve on best_len
+        for (;;) {
+            const uint8_t *cand = window + cur_match;
+            if (cand[offset] == end0 && cand[offset + 1] == end1 && cand[0] == sc0 && cand[1] == sc1) break;
+            if (--chain_length && (cur_match = s.prev[cur_match & s.w_mask]) > limit) continue;
+            return best_len;
+        }
+        const uint32_t len = compare256_wave(scan + 2, window + cur_match + 2, lane) + 2;
+        if (len > best_len) {
+            *match_start = cur_match;
+            if (len > s.lookahead) return s.lookahead;
+            best_len = len;
+            if (best_len >= s.nice_match) return best_len;
+            offset = best_len - 1;
+            end0 = scan[offset];
+            end1 = scan[offset + 1];
+        } else if (early_exit) {
+            break;
+        }
+        if (--chain_length && (cur_match = s.prev[cur_match & s.w_mask]) > limit) continue;
+        return best_len;
+    }
+    return best_len;
+}
+
+}  // namespace zr

@@ -51,6 +51,15 @@ _PROTOS = {
                                          C.c_void_p, C.c_void_p]),
     "zng_rocm_adler32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_crc32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_slide_hash_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zng_rocm_compare256_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_update_hash_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_quick_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zng_rocm_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zng_rocm_longest_match_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zng_rocm_chunkmemset_safe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]),
+    "zng_rocm_chunksize": (C.c_uint32, []),
     "zng_rocm_trace_begin": (C.c_int, [C.c_int]),
     "zng_rocm_trace_end": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "zng_rocm_adler32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
@@ -260,3 +269,70 @@ def trace_end(cap=4096):
     if n < 0:
         _check(n, "zng_rocm_trace_end")
     return [buf[i] for i in range(n)]
+
+
+# ---- deflate-side primitives on device-resident state --------------------------
+class DeflateView(C.Structure):
+    """zng_rocm_deflate_view (include/zng_rocm.h): the deflate_state subset the kernels read"""
+    _fields_ = [
+        ("window", C.c_void_p), ("prev", C.c_void_p), ("head", C.c_void_p),
+        ("w_size", C.c_uint32), ("w_mask", C.c_uint32),
+        ("lookahead", C.c_uint32), ("strstart", C.c_uint32), ("match_start", C.c_uint32),
+        ("prev_length", C.c_uint32), ("max_chain_length", C.c_uint32), ("good_match", C.c_uint32),
+        ("nice_match", C.c_int32), ("level", C.c_int32),
+    ]
+
+
+def views_to_device(views):
+    """pack a list of DeflateView into one uint8 CUDA tensor"""
+    import numpy as np
+    import torch
+    arr = (DeflateView * len(views))(*views)
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).cuda()
+
+
+def slide_hash_dev(d_views, nstreams, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_slide_hash_dev(_dev_ptr(d_views), nstreams, _stream_ptr(stream)), "zng_rocm_slide_hash_dev")
+
+
+def compare256_dev(base, off0, off1, out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_compare256_dev(_dev_ptr(base), _dev_ptr(off0), _dev_ptr(off1), off0.numel(), _dev_ptr(out),
+                                         _stream_ptr(stream)), "zng_rocm_compare256_dev")
+
+
+def update_hash_dev(val, out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_update_hash_dev(_dev_ptr(val), val.numel(), _dev_ptr(out), _stream_ptr(stream)),
+           "zng_rocm_update_hash_dev")
+
+
+def quick_insert_string_dev(d_views, nstreams, strs, head_out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_quick_insert_string_dev(_dev_ptr(d_views), nstreams, _dev_ptr(strs), _dev_ptr(head_out),
+                                                  _stream_ptr(stream)), "zng_rocm_quick_insert_string_dev")
+
+
+def insert_string_dev(d_views, nstreams, strs, counts, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_insert_string_dev(_dev_ptr(d_views), nstreams, _dev_ptr(strs), _dev_ptr(counts),
+                                            _stream_ptr(stream)), "zng_rocm_insert_string_dev")
+
+
+def longest_match_dev(d_views, nstreams, cur_match, len_out, start_out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_longest_match_dev(_dev_ptr(d_views), nstreams, _dev_ptr(cur_match), _dev_ptr(len_out),
+                                            _dev_ptr(start_out), _stream_ptr(stream)), "zng_rocm_longest_match_dev")
+
+
+def chunkmemset_safe_dev(base, out_off, from_off, lens, lefts, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_chunkmemset_safe_dev(_dev_ptr(base), _dev_ptr(out_off), _dev_ptr(from_off), _dev_ptr(lens),
+                                               _dev_ptr(lefts), out_off.numel(), _stream_ptr(stream)),
+           "zng_rocm_chunkmemset_safe_dev")
+
+
+def chunksize():
+    return lib().zng_rocm_chunksize()
