@@ -159,6 +159,44 @@ int zng_rocm_chunkmemset_safe_dev(uint8_t *d_base, const uint64_t *d_out_off, co
 /* slot `chunksize` (chunkset_tpl.h:9-11): store granule of the device copy kernels (bytes). */
 uint32_t zng_rocm_chunksize(void);
 
+/* ---- inflate: host bitstream decode -> token stream -> device copy resolution -------------
+ * The split of slot `inflate_fast` (inffast_tpl.h:53-318): the sequential Huffman decode loop
+ * (:151-226) runs on the host and emits TOKENS instead of stores; the literal stores and match
+ * copies (:155-171, :228-279 CHUNKCOPY / CHUNKMEMSET / chunkcopy_safe) are resolved on the
+ * device, all segments in parallel.
+ *   token (uint32): bit31 = 0 -> run of `tok` literals, taken in order from `literals`
+ *                   bit31 = 1 -> match: length = ((tok >> 16) & 0xff) + 3, distance = (tok & 0xffff) + 1
+ *   segs: (nsegs + 1) triples {first token, first output byte, first literal}; every segment but
+ *         the last holds >= 128 KiB (and < 128 KiB + 258) of output, so a match never reaches
+ *         further back than the previous segment.
+ * status / msg follow zlib: 1 = Z_STREAM_END, -3 = Z_DATA_ERROR with the reference's strm->msg text
+ * (inflate.c:735-917, inffast_tpl.h:189-226), -5 = input ended early, -4 = out of memory.  On an
+ * error the tokens describe everything decoded before the bad symbol. */
+typedef struct zng_rocm_inflate_tokens {
+    uint32_t   *tokens;    size_t ntokens;
+    uint8_t    *literals;  size_t nliterals;
+    uint64_t   *segs;      size_t nsegs;
+    uint64_t    out_len;
+    size_t      in_used;
+    int         status;
+    const char *msg;
+} zng_rocm_inflate_tokens;
+
+int  zng_rocm_inflate_tokens_decode(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *out);
+void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
+/* Device stage on device-resident token arrays.  d_symbols: workspace of out_len uint16_t;
+ * d_out: out_len bytes.  Three launches: per-segment resolution into 16-bit symbols (a symbol
+ * >= 256 names a byte of the previous segment's last 32 KiB), the sequential context chain, and the
+ * final translate. */
+int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
+                                  size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
+                                  uint8_t *d_out, uint64_t out_len, void *stream);
+/* One-shot raw inflate (windowBits < 0): host stream in, plaintext left in device memory at d_dst.
+ * Returns the zlib status of the decode (1 = Z_STREAM_END) or a negative ZNG_ROCM_E* / Z_* code;
+ * *out_len = bytes produced.  -5 also when dst_cap is too small. */
+int  zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
+                          void *stream);
+
 /* ---- measurement hooks --------------------------------------------------
  * Between trace_begin and trace_end every launch of the DOMINANT kernel of a
  * *_dev entry point (the streaming kernel, not its finalize step) is bracketed

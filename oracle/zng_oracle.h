@@ -84,6 +84,22 @@ uint32_t   oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match);
 uint32_t   oracle_chunksize(void);
 uint8_t   *oracle_chunkmemset_safe(uint8_t *out, uint8_t *from, unsigned len, unsigned left);
 
+/* ---- raw inflate (inflate.c / inffast_tpl.h / inftrees.c behaviour) ---- */
+#define ORACLE_Z_OK           0
+#define ORACLE_Z_STREAM_END   1
+#define ORACLE_Z_DATA_ERROR (-3)
+#define ORACLE_Z_BUF_ERROR  (-5)     /* input ended early, or dst full */
+
+typedef struct oracle_inflate_result {
+    int         status;
+    const char *msg;        /* the reference's strm->msg text for data errors */
+    size_t      out_len;    /* bytes produced (also on error: everything before the bad symbol) */
+    size_t      in_used;
+} oracle_inflate_result;
+
+int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                       oracle_inflate_result *res);
+
 #ifdef __cplusplus
 }
 #endif

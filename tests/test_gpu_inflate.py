@@ -1,0 +1,106 @@
+"""GPU parity: inflate copy-resolution stage (device) behind the host token decoder.
+Bit-exact vs the plaintext / the oracle inflater; streams come from CPython's zlib (an independent
+RFC 1951 encoder) at several levels, plus the reference's infcover streams."""
+import importlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import inflate_util
+import synth
+from gpu_common import product, torch_mod
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "inflate_kat.json")))
+
+
+@pytest.fixture(scope="module")
+def inf():
+    zr = product()
+    zr.init()
+    return importlib.import_module("zlib-ng_amd.inflate")
+
+
+def _raw_deflate(data, level, strategy=zlib.Z_DEFAULT_STRATEGY):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def test_infcover_streams_on_device(inf):
+    for r in KAT["rows"]:
+        src = bytes(int(t, 16) for t in r["hex"].split())
+        dec = inf.decode_tokens(src)
+        ost, omsg, oout, _ = inflate_util.oracle_inflate(src, cap=70000)
+        got = inf.resolve_dev(dec).cpu().numpy().tobytes()
+        assert (dec.status, dec.msg) == (ost, omsg)
+        assert got == oout, r
+
+
+def test_corpus_levels(inf):
+    rng = np.random.default_rng(3)
+    cases = {
+        "mix": synth.silesia_like(3 << 20, seed=7, seg_bytes=512 << 10).tobytes(),
+        "zeros": b"\0" * 900000,                                   # distance-1 runs across many segments
+        "period7": (b"abcdefg" * 40000),
+        "random": rng.integers(0, 256, size=500000, dtype=np.uint8).tobytes(),
+        "empty": b"",
+        "one": b"x",
+        "far": (rng.integers(0, 256, size=32768, dtype=np.uint8).tobytes()) * 9,   # distance 32768 everywhere
+    }
+    for name, data in cases.items():
+        for level in (0, 1, 6, 9):
+            comp = _raw_deflate(data, level)
+            dec = inf.decode_tokens(comp)
+            assert dec.status == 1 and dec.out_len == len(data)
+            got = inf.resolve_dev(dec).cpu().numpy().tobytes()
+            assert got == data, (name, level)
+    comp = _raw_deflate(cases["mix"], 6, zlib.Z_FIXED)
+    assert inf.resolve_dev(inf.decode_tokens(comp)).cpu().numpy().tobytes() == cases["mix"]
+
+
+def test_one_shot_inflate_raw_and_errors(inf):
+    torch = torch_mod()
+    data = synth.silesia_like(2 << 20, seed=11, seg_bytes=256 << 10).tobytes()
+    comp = _raw_deflate(data, 6)
+    dst = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+    rc, n = inf.inflate_raw(comp, dst)
+    assert rc == 1 and n == len(data)
+    assert dst[:n].cpu().numpy().tobytes() == data
+    # too-small destination
+    small = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    rc, n = inf.inflate_raw(comp, small)
+    assert rc == -5
+    # corrupt stream: status, and the bytes before the bad symbol, match the oracle
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x10
+    ost, omsg, oout, _ = inflate_util.oracle_inflate(bytes(bad), cap=4 * len(data))
+    dst2 = torch.zeros(4 * len(data), dtype=torch.uint8, device="cuda")
+    rc, n = inf.inflate_raw(bytes(bad), dst2)
+    assert rc == ost
+    if ost in (1, -3):
+        assert n == len(oout) and dst2[:n].cpu().numpy().tobytes() == oout
+    # truncated stream
+    rc, n = inf.inflate_raw(comp[:len(comp) // 2], dst)
+    assert rc == -5 and data.startswith(dst[:n].cpu().numpy().tobytes())
+
+
+def test_cfg3_scale_stream(inf):
+    """BASELINE.json configs[2] shape at 64 MiB of plaintext (the 256 MiB run lives in bench_configs.py):
+    level-6 raw stream of the Silesia-like mix, bit-exact against the plaintext on device."""
+    torch = torch_mod()
+    plain = synth.silesia_like(64 << 20, seed=0x5EED0003, seg_bytes=4 << 20)
+    comp = _raw_deflate(plain.tobytes(), 6)
+    dec = inf.decode_tokens(comp)
+    assert dec.status == 1 and dec.out_len == plain.size and dec.nsegs >= 500
+    got = inf.resolve_dev(dec)
+    want = torch.from_numpy(plain).cuda()
+    assert torch.equal(got, want)
+    # size-independent property: checksum of the device output == checksum of the plaintext (device adler/crc)
+    zr = product()
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zr.adler32_crc32_dev(got, out)
+    assert [v & 0xffffffff for v in out.tolist()] == [zlib.adler32(plain.tobytes()), zlib.crc32(plain.tobytes())]

@@ -1,0 +1,127 @@
+"""CPU tests of the product's host inflate stage (token decoder): the reference's infcover streams
+(status and strm->msg text), parity with the oracle inflater, and a token replay in numpy that must
+reproduce the plaintext.  No GPU needed: the device stage is covered by tests/test_gpu_inflate.py."""
+import importlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import deflate_state_util as dsu
+import inflate_util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "inflate_kat.json")))
+
+
+def _inflate_mod():
+    importlib.import_module("zlib-ng_amd")
+    return importlib.import_module("zlib-ng_amd.inflate")
+
+
+def replay(dec):
+    """reference interpreter of the token format (test-side checker)"""
+    out = bytearray()
+    lit = dec.literals.tobytes()
+    lp = 0
+    for tok in dec.tokens.tolist():
+        if tok >> 31:
+            ln = ((tok >> 16) & 0xff) + 3
+            dist = (tok & 0xffff) + 1
+            assert dist <= len(out)
+            if dist >= ln:
+                out += out[len(out) - dist:len(out) - dist + ln]
+            else:
+                for _ in range(ln):
+                    out.append(out[-dist])
+        else:
+            out += lit[lp:lp + tok]
+            lp += tok
+    assert lp == len(lit)
+    return bytes(out)
+
+
+def test_infcover_rows_status_and_message():
+    inf = _inflate_mod()
+    for r in KAT["rows"]:
+        src = bytes(int(t, 16) for t in r["hex"].split())
+        dec = inf.decode_tokens(src)
+        ost, omsg, oout, oused = inflate_util.oracle_inflate(src, cap=70000)
+        assert dec.status == ost and dec.msg == omsg, (r, dec.status, dec.msg, ost, omsg)
+        assert replay(dec) == oout and dec.out_len == len(oout)
+        if r["kind"] == "try":
+            if r["expect_data_error"]:
+                assert dec.status == -3 and dec.msg == r["id"], r
+            else:
+                assert dec.status != -3, r
+        elif not r["chunking_dependent"]:
+            assert dec.status == (-3 if r["expect"] == "Z_DATA_ERROR" else 1), r
+
+
+def _corpus():
+    rng = np.random.default_rng(12)
+    yield "text", dsu.texty(700000, 5).tobytes()
+    yield "random", rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()
+    yield "zeros", b"\0" * 400000
+    yield "empty", b""
+    yield "period3", (b"abc" * 9 + b"xyz!") * 20000
+    yield "dna", bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=500000))
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_streams_from_python_zlib(level):
+    inf = _inflate_mod()
+    for name, data in _corpus():
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED):
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            comp = c.compress(data) + c.flush()
+            dec = inf.decode_tokens(comp)
+            assert dec.status == 1 and dec.in_used == len(comp), (name, level)
+            assert dec.out_len == len(data)
+            assert replay(dec) == data, (name, level)
+            # segment table: monotone, >= 128 KiB each but the last, terminal triple closes the arrays
+            segs = dec.segs.reshape(-1, 3)
+            assert segs.shape[0] == dec.nsegs + 1
+            assert tuple(segs[0]) == (0, 0, 0)
+            assert tuple(segs[-1]) == (dec.tokens.size, len(data), dec.literals.size)
+            sizes = np.diff(segs[:, 1].astype(np.int64))
+            assert (sizes[:-1] >= 128 * 1024).all() and (sizes <= 128 * 1024 + 258).all()
+
+
+def test_truncated_and_corrupt_inputs_match_oracle():
+    inf = _inflate_mod()
+    data = dsu.texty(90000, 8).tobytes()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    rng = np.random.default_rng(0)
+    for cut in (0, 1, 2, 5, len(comp) // 3, len(comp) - 1):
+        dec = inf.decode_tokens(comp[:cut])
+        ost, omsg, oout, _ = inflate_util.oracle_inflate(comp[:cut], cap=len(data) + 64)
+        assert dec.status == ost == -5
+        # a starved decoder may stop a symbol earlier or later than the oracle; both are prefixes
+        got = replay(dec)
+        assert data.startswith(got) and data.startswith(oout)
+    for trial in range(300):
+        bad = bytearray(comp)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        dec = inf.decode_tokens(bytes(bad))
+        ost, omsg, oout, _ = inflate_util.oracle_inflate(bytes(bad), cap=4 * len(data) + 1024)
+        if ost == -5 and omsg == "output buffer full":
+            continue
+        assert dec.status == ost, (trial, pos, dec.status, dec.msg, ost, omsg)
+        if ost == -3:
+            assert dec.msg == omsg, (trial, pos)
+            assert replay(dec) == oout
+        elif ost == 1:
+            assert replay(dec) == oout
+
+
+def test_zlib_wrapped_reference_stream():
+    inf = _inflate_mod()
+    z = KAT["zlib_stream"]
+    raw = bytes.fromhex(z["hex"])[2:-4]
+    dec = inf.decode_tokens(raw)
+    assert dec.status == 1 and replay(dec) == z["plaintext"].encode()

@@ -1,0 +1,89 @@
+"""Pin the oracle's raw inflate: the reference's infcover streams (status + strm->msg text), the
+test_inflate_adler32 stream, and CPython's zlib as an independent RFC 1951 codec."""
+import ctypes as C
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import inflate_util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "inflate_kat.json")))
+
+
+def test_infcover_try_rows():
+    for r in KAT["rows"]:
+        if r["kind"] != "try":
+            continue
+        src = bytes(int(t, 16) for t in r["hex"].split())
+        st, msg, out, used = inflate_util.oracle_inflate(src, cap=len(src) * 8 + 1024)
+        if r["expect_data_error"]:
+            assert st == -3 and msg == r["id"], (r, st, msg)
+        else:
+            assert st != -3, (r, msg)
+        # independent decoder agrees on error vs no error
+        d = zlib.decompressobj(-15)
+        try:
+            d.decompress(src)
+            py_err = False
+        except zlib.error:
+            py_err = True
+        assert py_err == r["expect_data_error"], r
+
+
+def test_infcover_inf_rows():
+    for r in KAT["rows"]:
+        if r["kind"] != "inf" or r["chunking_dependent"]:
+            continue
+        src = bytes(int(t, 16) for t in r["hex"].split())
+        st, msg, out, used = inflate_util.oracle_inflate(src, cap=70000)
+        if r["expect"] == "Z_DATA_ERROR":
+            assert st == -3, (r, st, msg)
+        else:
+            assert st == 1, (r, st, msg)
+
+
+def test_zlib_wrapped_reference_stream():
+    z = KAT["zlib_stream"]
+    raw = bytes.fromhex(z["hex"])[2:-4]
+    st, msg, out, used = inflate_util.oracle_inflate(raw, cap=1024)
+    assert st == 1 and out == z["plaintext"].encode()
+    assert zlib.adler32(out) == z["adler32"]
+    assert used == len(raw)
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_against_python_zlib_streams(level):
+    import deflate_state_util as dsu
+    rng = np.random.default_rng(level)
+    for kind in range(5):
+        if kind == 0:
+            data = dsu.texty(200000, 77 + kind).tobytes()
+        elif kind == 1:
+            data = rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            data = b"\0" * 100000
+        elif kind == 3:
+            data = b""
+        else:
+            data = (b"abc" * 7 + b"xyz") * 3000
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY):
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+            comp = c.compress(data) + c.flush()
+            st, msg, out, used = inflate_util.oracle_inflate(comp, cap=len(data) + 16)
+            assert st == 1 and out == data and used == len(comp)
+            # truncated input is reported as "need more", never as corrupt
+            st2, _, out2, _ = inflate_util.oracle_inflate(comp[:len(comp) // 2], cap=len(data) + 16)
+            assert st2 in (-5,) or (len(comp) < 2)
+            assert data.startswith(out2)
+
+
+def test_output_cap():
+    data = b"hello hello hello hello" * 100
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    st, msg, out, used = inflate_util.oracle_inflate(comp, cap=100)
+    assert st == -5 and msg == "output buffer full" and data.startswith(out)

@@ -1,0 +1,475 @@
+// inflate_host.cpp -- host stage of the arch/rocm inflate path: the sequential DEFLATE bitstream
+// (RFC 1951) is decoded on the host into a TOKEN stream; the device resolves every copy
+// (inflate_resolve.hip).  This is the split of zlib-ng's inflate_fast (inffast_tpl.h:53-318) at the
+// point where a decoded symbol becomes a store: the table-driven decode loop (:151-226) stays here,
+// the literal stores and CHUNKCOPY/CHUNKMEMSET match copies (:155-171, :228-279) become device work.
+//
+// Behaviour mirrored from the reference (error texts are the reference's strm->msg strings):
+//   block header / stored / dynamic header checks   inflate.c:735-917
+//   code validity rules                             inftrees.c:108-131
+//   length/distance base+extra tables               inftrees.c:52-65 (RFC 1951 3.2.5)
+//   64-bit refill, root tables of 10 (lit/len) and 9 (dist) bits   inffast_tpl.h:44-46,142-147; inflate.c:899,909
+// One-shot contract: the whole raw stream is in `src`; "invalid distance too far back" = distance
+// larger than the bytes produced so far (inffast_tpl.h:198-226 with no prior window).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/zng_rocm.h"
+
+namespace {
+
+enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
+
+// decode-table entry (4 bytes, like the reference's `code`, inftrees.h:27-31, but own encoding)
+struct Ent {
+    uint8_t  kind;      // K_* below
+    uint8_t  bits;      // code bits to drop (root entries: <= root; sub entries: total - root)
+    uint16_t val;       // literal byte | base value | sub-table offset
+};
+enum : uint8_t {
+    K_LIT = 0,          // val = byte
+    K_BASE = 16,        // | extra-bit count (0..13): val = base length / distance
+    K_EOB = 32,
+    K_BAD = 64,
+    K_LINK = 128,       // | sub-table index bits: val = offset of the sub-table
+};
+
+const uint16_t kLenBase[31] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+                               35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0};
+const uint8_t kLenExtra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+                               3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
+const uint16_t kDistBase[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
+                                257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                                8193, 12289, 16385, 24577, 0, 0};
+const uint8_t kDistExtra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
+                                7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+
+enum TableKind { T_CODES, T_LENS, T_DISTS };
+
+inline unsigned bitrev(unsigned code, int len) {
+    unsigned r = 0;
+    for (int i = 0; i < len; ++i) {
+        r = (r << 1) | (code & 1u);
+        code >>= 1;
+    }
+    return r;
+}
+
+// Builds a two-level table.  Returns 0, or -1 for an invalid length set (inftrees.c:108-131).
+// `table` needs room for (1<<root) + sub-tables: 1334 entries suffice for root 10 / 286 symbols
+// and 402 for root 9 / 30 symbols worst case sized generously below.
+int build_table(TableKind kind, const uint16_t *lens, int n, int root, Ent *table, int *root_out) {
+    int count[16] = {0};
+    for (int s = 0; s < n; ++s) count[lens[s]]++;
+    int max = 15;
+    while (max >= 1 && count[max] == 0) --max;
+    if (max == 0) {                                   // no codes: every lookup is an error
+        table[0] = table[1] = Ent{K_BAD, 1, 0};
+        *root_out = 1;
+        return 0;
+    }
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left = (left << 1) - count[len];
+        if (left < 0) return -1;                      // over-subscribed
+    }
+    if (left > 0 && (kind == T_CODES || max != 1)) return -1;   // incomplete
+    if (root > max) root = max;
+    int min = 1;
+    while (min < max && count[min] == 0) ++min;
+    if (root < min) root = min;
+    *root_out = root;
+
+    const int root_size = 1 << root;
+    for (int i = 0; i < root_size; ++i) table[i] = Ent{K_BAD, (uint8_t)root, 0};
+
+    // canonical first code of each length
+    unsigned next_code[16];
+    unsigned code = 0;
+    count[0] = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code = (code + (unsigned)count[len - 1]) << 1;
+        next_code[len] = code;
+    }
+    // pass 1: how deep is each root prefix (longest code sharing it)
+    static thread_local uint8_t depth[1 << 10];
+    memset(depth, 0, (size_t)root_size);
+    unsigned nc[16];
+    memcpy(nc, next_code, sizeof(nc));
+    for (int s = 0; s < n; ++s) {
+        int len = lens[s];
+        if (len > root) {
+            unsigned rev = bitrev(nc[len], len);
+            unsigned pre = rev & (unsigned)(root_size - 1);
+            if (depth[pre] < len - root) depth[pre] = (uint8_t)(len - root);
+        }
+        if (len) nc[len]++;
+    }
+    int used = root_size;
+    for (int pre = 0; pre < root_size; ++pre) {
+        if (depth[pre]) {
+            table[pre] = Ent{(uint8_t)(K_LINK | depth[pre]), (uint8_t)root, (uint16_t)used};
+            int sz = 1 << depth[pre];
+            for (int i = 0; i < sz; ++i) table[used + i] = Ent{K_BAD, depth[pre], 0};
+            used += sz;
+        }
+    }
+    // pass 2: fill
+    memcpy(nc, next_code, sizeof(nc));
+    for (int s = 0; s < n; ++s) {
+        int len = lens[s];
+        if (!len) continue;
+        unsigned rev = bitrev(nc[len]++, len);
+        Ent e;
+        if (kind == T_CODES) {
+            e = Ent{K_LIT, 0, (uint16_t)s};
+        } else if (kind == T_LENS) {
+            if (s < 256) e = Ent{K_LIT, 0, (uint16_t)s};
+            else if (s == 256) e = Ent{K_EOB, 0, 0};
+            else if (s - 257 < 29) e = Ent{(uint8_t)(K_BASE | kLenExtra[s - 257]), 0, kLenBase[s - 257]};
+            else e = Ent{K_BAD, 0, 0};                            // 286, 287: inftrees.c lext 203/77 = invalid
+        } else {
+            if (s < 30) e = Ent{(uint8_t)(K_BASE | kDistExtra[s]), 0, kDistBase[s]};
+            else e = Ent{K_BAD, 0, 0};
+        }
+        if (len <= root) {
+            e.bits = (uint8_t)len;
+            for (unsigned i = rev; i < (unsigned)root_size; i += 1u << len) table[i] = e;
+        } else {
+            unsigned pre = rev & (unsigned)(root_size - 1);
+            int sub_bits = table[pre].kind & 15;
+            Ent *sub = table + table[pre].val;
+            e.bits = (uint8_t)(len - root);
+            for (unsigned i = rev >> root; i < (1u << sub_bits); i += 1u << (len - root)) sub[i] = e;
+        }
+    }
+    return 0;
+}
+
+struct Out {
+    zng_rocm_inflate_tokens *t;
+    size_t tok_cap, lit_cap, seg_cap;
+    uint64_t out_pos;           // bytes the stream has produced
+    uint64_t seg_out;           // out_pos at which the current segment started
+    uint32_t run;               // literals accumulated since the last token
+    bool oom;
+};
+
+constexpr uint64_t kSegTarget = 128u << 10;    // a segment closes once it holds >= 128 KiB of output
+constexpr uint32_t kMaxRun = 0x7fffffffu;
+
+inline void grow(void **p, size_t *cap, size_t need, size_t elt, bool *oom) {
+    if (need <= *cap) return;
+    size_t ncap = *cap ? *cap : 4096;
+    while (ncap < need) ncap += ncap >> 1;
+    void *q = realloc(*p, ncap * elt);
+    if (!q) { *oom = true; return; }
+    *p = q;
+    *cap = ncap;
+}
+
+inline void push_token(Out &o, uint32_t tok) {
+    zng_rocm_inflate_tokens *t = o.t;
+    if (t->ntokens + 1 > o.tok_cap) grow((void **)&t->tokens, &o.tok_cap, t->ntokens + 1, 4, &o.oom);
+    if (!o.oom) t->tokens[t->ntokens++] = tok;
+}
+
+inline void flush_run(Out &o) {
+    if (o.run) {
+        push_token(o, o.run);
+        o.run = 0;
+    }
+}
+
+inline void maybe_new_segment(Out &o) {
+    // only called at a token boundary (run == 0)
+    if (o.out_pos - o.seg_out >= kSegTarget) {
+        zng_rocm_inflate_tokens *t = o.t;
+        if ((t->nsegs + 2) * 3 > o.seg_cap) grow((void **)&t->segs, &o.seg_cap, (t->nsegs + 2) * 3, 8, &o.oom);
+        if (o.oom) return;
+        uint64_t *s = t->segs + 3 * t->nsegs++;
+        s[0] = t->ntokens;
+        s[1] = o.out_pos;
+        s[2] = t->nliterals;
+        o.seg_out = o.out_pos;
+    }
+}
+
+inline void reserve_literals(Out &o, size_t more) {
+    zng_rocm_inflate_tokens *t = o.t;
+    if (t->nliterals + more > o.lit_cap) grow((void **)&t->literals, &o.lit_cap, t->nliterals + more, 1, &o.oom);
+}
+
+struct Bits {
+    const uint8_t *next, *end;
+    uint64_t hold;
+    unsigned cnt;
+    // make at least `n` (<= 32) bits available; false if the input is exhausted
+    inline bool need(unsigned n) {
+        while (cnt < n) {
+            if (next == end) return false;
+            hold |= (uint64_t)*next++ << cnt;
+            cnt += 8;
+        }
+        return true;
+    }
+    inline void refill_fast() {          // caller guarantees >= 8 readable bytes (inffast_tpl.h:142-147)
+        uint64_t w;
+        memcpy(&w, next, 8);
+        hold |= w << cnt;
+        unsigned adv = (63 - cnt) >> 3;
+        next += adv;
+        cnt += adv << 3;
+    }
+    inline unsigned peek(unsigned n) const { return (unsigned)(hold & ((1ull << n) - 1)); }
+    inline void drop(unsigned n) { hold >>= n; cnt -= n; }
+};
+
+#define FAIL(m) do { t->status = Z_DATA_ERROR_; t->msg = (m); goto done; } while (0)
+#define STARVE() do { t->status = Z_BUF_ERROR_; t->msg = "input ended before the final block"; goto done; } while (0)
+
+int decode_stream(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *t) {
+    Out o;
+    o.t = t;
+    o.tok_cap = o.lit_cap = o.seg_cap = 0;
+    o.out_pos = o.seg_out = 0;
+    o.run = 0;
+    o.oom = false;
+    Bits b{src, src + src_len, 0, 0};
+    static thread_local Ent lentab[(1 << 10) + 1024], disttab[(1 << 9) + 512], cltab[(1 << 7) + 128];
+    int lenroot = 0, distroot = 0, clroot = 0;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint16_t lens[320];
+    bool last = false;
+
+    // segment 0
+    grow((void **)&t->segs, &o.seg_cap, 6, 8, &o.oom);
+    if (o.oom) goto oom;
+    t->segs[0] = t->segs[1] = t->segs[2] = 0;
+    t->nsegs = 1;
+    grow((void **)&t->tokens, &o.tok_cap, src_len / 2 + 1024, 4, &o.oom);
+    grow((void **)&t->literals, &o.lit_cap, src_len + 4096, 1, &o.oom);
+    if (o.oom) goto oom;
+    t->status = Z_OK_;
+    t->msg = "";
+
+    while (!last) {
+        if (!b.need(3)) STARVE();
+        last = b.peek(1);
+        b.drop(1);
+        unsigned type = b.peek(2);
+        b.drop(2);
+        if (type == 3) FAIL("invalid block type");
+        if (type == 0) {
+            b.drop(b.cnt & 7);                                   // BYTEBITS (inflate.c:761)
+            if (!b.need(32)) STARVE();
+            unsigned len = b.peek(16);
+            unsigned nlen = (unsigned)((b.hold >> 16) & 0xffff);
+            if (len != (nlen ^ 0xffffu)) FAIL("invalid stored block lengths");
+            b.drop(32);
+            // whole bytes still sitting in the bit buffer go back to the byte stream
+            b.next -= b.cnt >> 3;
+            b.hold = 0;
+            b.cnt = 0;
+            size_t avail = (size_t)(b.end - b.next);
+            size_t n = len < avail ? len : avail;
+            // stored bytes are literals of the token stream
+            size_t done_n = 0;
+            while (done_n < n && !o.oom) {
+                size_t room = (size_t)(kSegTarget - (o.out_pos - o.seg_out));
+                if (room == 0) {
+                    flush_run(o);
+                    maybe_new_segment(o);
+                    continue;
+                }
+                size_t piece = n - done_n < room ? n - done_n : room;
+                if (piece > kMaxRun - o.run) piece = kMaxRun - o.run;
+                reserve_literals(o, piece);
+                if (o.oom) break;
+                memcpy(t->literals + t->nliterals, b.next + done_n, piece);
+                t->nliterals += piece;
+                o.run += (uint32_t)piece;
+                o.out_pos += piece;
+                done_n += piece;
+            }
+            if (o.oom) goto oom;
+            b.next += n;
+            if (n < len) STARVE();
+            continue;
+        }
+        if (type == 1) {
+            int s = 0;
+            for (; s < 144; ++s) lens[s] = 8;                     // RFC 1951 3.2.6
+            for (; s < 256; ++s) lens[s] = 9;
+            for (; s < 280; ++s) lens[s] = 7;
+            for (; s < 288; ++s) lens[s] = 8;
+            build_table(T_LENS, lens, 288, 9, lentab, &lenroot);
+            for (s = 0; s < 32; ++s) lens[s] = 5;
+            build_table(T_DISTS, lens, 32, 5, disttab, &distroot);
+        } else {
+            if (!b.need(14)) STARVE();
+            unsigned nlen = b.peek(5) + 257; b.drop(5);
+            unsigned ndist = b.peek(5) + 1;  b.drop(5);
+            unsigned ncode = b.peek(4) + 4;  b.drop(4);
+            if (nlen > 286 || ndist > 30) FAIL("too many length or distance symbols");
+            uint16_t cl[19] = {0};
+            for (unsigned i = 0; i < ncode; ++i) {
+                if (!b.need(3)) STARVE();
+                cl[order[i]] = (uint16_t)b.peek(3);
+                b.drop(3);
+            }
+            if (build_table(T_CODES, cl, 19, 7, cltab, &clroot)) FAIL("invalid code lengths set");
+            unsigned have = 0;
+            while (have < nlen + ndist) {
+                Ent e;
+                for (;;) {                                         // inflate.c:841-845
+                    e = cltab[b.peek((unsigned)clroot)];
+                    if (e.bits <= b.cnt) break;
+                    if (b.next == b.end) STARVE();
+                    b.hold |= (uint64_t)*b.next++ << b.cnt;
+                    b.cnt += 8;
+                }
+                // an empty code-length code yields K_BAD entries of 1 bit with val 0: every entry reads
+                // as length 0 (inftrees.c:114-122 + inflate.c:846-849)
+                unsigned sym = e.val;
+                if (sym < 16) {
+                    b.drop(e.bits);
+                    lens[have++] = (uint16_t)sym;
+                    continue;
+                }
+                unsigned rep, val = 0;
+                if (sym == 16) {
+                    if (!b.need(e.bits + 2u)) STARVE();
+                    b.drop(e.bits);
+                    if (have == 0) FAIL("invalid bit length repeat");
+                    val = lens[have - 1];
+                    rep = 3 + b.peek(2);
+                    b.drop(2);
+                } else if (sym == 17) {
+                    if (!b.need(e.bits + 3u)) STARVE();
+                    b.drop(e.bits);
+                    rep = 3 + b.peek(3);
+                    b.drop(3);
+                } else {
+                    if (!b.need(e.bits + 7u)) STARVE();
+                    b.drop(e.bits);
+                    rep = 11 + b.peek(7);
+                    b.drop(7);
+                }
+                if (have + rep > nlen + ndist) FAIL("invalid bit length repeat");
+                while (rep--) lens[have++] = (uint16_t)val;
+            }
+            if (lens[256] == 0) FAIL("invalid code -- missing end-of-block");
+            if (build_table(T_LENS, lens, (int)nlen, 10, lentab, &lenroot)) FAIL("invalid literal/lengths set");
+            if (build_table(T_DISTS, lens + nlen, (int)ndist, 9, disttab, &distroot)) FAIL("invalid distances set");
+        }
+
+        // ---- symbol loop (the decode half of inflate_fast) ----------------------------------
+        for (;;) {
+            if (o.oom) goto oom;
+            reserve_literals(o, 1);
+            if (o.oom) goto oom;
+            // a symbol needs at most 15+5 + 15+13 = 48 bits
+            if ((size_t)(b.end - b.next) >= 8) {
+                b.refill_fast();
+            } else {
+                (void)b.need(48);                   // best effort near the end; checked below
+            }
+            Ent e = lentab[b.peek((unsigned)lenroot)];
+            if (e.kind & K_LINK) {
+                unsigned sub = e.kind & 15;
+                unsigned idx = (unsigned)((b.hold >> e.bits) & ((1u << sub) - 1));
+                Ent e2 = lentab[e.val + idx];
+                if (b.cnt < (unsigned)e.bits + e2.bits) STARVE();
+                b.drop(e.bits);
+                e = e2;
+            }
+            if (b.cnt < e.bits) STARVE();
+            if (e.kind == K_LIT) {
+                b.drop(e.bits);
+                t->literals[t->nliterals++] = (uint8_t)e.val;
+                o.out_pos++;
+                if (++o.run == kMaxRun || o.out_pos - o.seg_out >= kSegTarget) {
+                    flush_run(o);
+                    maybe_new_segment(o);
+                }
+                continue;
+            }
+            if (e.kind & K_BAD) FAIL("invalid literal/length code");
+            if (e.kind & K_EOB) {
+                b.drop(e.bits);
+                break;
+            }
+            // length
+            unsigned xb = e.kind & 15;
+            if (b.cnt < (unsigned)e.bits + xb) STARVE();
+            b.drop(e.bits);
+            unsigned len = e.val + b.peek(xb);
+            b.drop(xb);
+            // distance
+            Ent d = disttab[b.peek((unsigned)distroot)];
+            if (d.kind & K_LINK) {
+                unsigned sub = d.kind & 15;
+                unsigned idx = (unsigned)((b.hold >> d.bits) & ((1u << sub) - 1));
+                Ent d2 = disttab[d.val + idx];
+                if (b.cnt < (unsigned)d.bits + d2.bits) STARVE();
+                b.drop(d.bits);
+                d = d2;
+            }
+            if (b.cnt < d.bits) STARVE();
+            if (d.kind & K_BAD) FAIL("invalid distance code");
+            xb = d.kind & 15;
+            if (b.cnt < (unsigned)d.bits + xb) STARVE();
+            b.drop(d.bits);
+            unsigned dist = d.val + b.peek(xb);
+            b.drop(xb);
+            if (dist > o.out_pos) FAIL("invalid distance too far back");
+            flush_run(o);
+            maybe_new_segment(o);
+            push_token(o, 0x80000000u | ((len - 3) << 16) | (dist - 1));
+            o.out_pos += len;
+        }
+    }
+    t->status = Z_STREAM_END_;
+done:
+    if (o.oom) goto oom;
+    flush_run(o);
+    if (o.oom) goto oom;
+    {
+        // terminal triple
+        if ((t->nsegs + 1) * 3 > o.seg_cap) grow((void **)&t->segs, &o.seg_cap, (t->nsegs + 1) * 3, 8, &o.oom);
+        if (o.oom) goto oom;
+        uint64_t *s = t->segs + 3 * t->nsegs;
+        s[0] = t->ntokens;
+        s[1] = o.out_pos;
+        s[2] = t->nliterals;
+    }
+    t->out_len = o.out_pos;
+    t->in_used = (size_t)(b.next - src) - (b.cnt >> 3);
+    return t->status;
+oom:
+    t->status = Z_MEM_ERROR_;
+    t->msg = "out of memory";
+    return t->status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zng_rocm_inflate_tokens_decode(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *out) {
+    if (!out || (!src && src_len)) return ZNG_ROCM_EINVAL;
+    memset(out, 0, sizeof(*out));
+    return decode_stream(src, src_len, out);
+}
+
+void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t) {
+    if (!t) return;
+    free(t->tokens);
+    free(t->literals);
+    free(t->segs);
+    memset(t, 0, sizeof(*t));
+}
+
+}  // extern "C"

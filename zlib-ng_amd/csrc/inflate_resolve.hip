@@ -1,0 +1,192 @@
+// inflate_resolve.hip -- device stage of the inflate path: turn the host decoder's token stream into
+// plaintext in HBM.  This is the store half of zlib-ng's inflate_fast (inffast_tpl.h:155-171 literal
+// stores, :228-279 match copies via CHUNKCOPY / CHUNKMEMSET, chunkset_tpl.h:24-227) re-designed for a
+// machine that wants thousands of independent copy streams:
+//
+//   K1 segments  one wavefront per >=128 KiB output segment walks its tokens in order and writes 16-bit
+//                SYMBOLS: a literal byte, or 256 + k meaning "byte k of the 32 KiB that precede this
+//                segment".  Copies inside the segment move symbols, so unresolved references
+//                propagate by themselves; no segment waits for another.
+//   K2 context   one workgroup walks the segments in order and finalises only the last 32 KiB of each
+//                (the only bytes a later segment can name) -- 32 KiB per step instead of the whole stream.
+//   K3 translate all symbols -> bytes, fully parallel: 2N read + N written, HBM-bound.
+//
+// Algorithmic bytes: C + U per stream; the symbol detour adds 4U of HBM traffic.
+#include "context.h"
+
+namespace zr {
+
+constexpr long long kCtx = 32768;         // MAX_WBITS 15: a distance never exceeds this
+
+__global__ __launch_bounds__(256)
+void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t *__restrict__ literals,
+                             const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
+    const int lane = threadIdx.x & 63;
+    const size_t seg = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (seg >= nsegs) return;
+    const uint64_t t0 = segs[3 * seg], t1 = segs[3 * seg + 3];
+    const long long o0 = (long long)segs[3 * seg + 1];
+    long long op = o0;
+    unsigned long long lp = segs[3 * seg + 2];
+    const long long ctx_base = o0 - kCtx;
+
+    for (uint64_t t = t0; t < t1; ++t) {
+        const uint32_t tok = tokens[t];
+        if (!(tok >> 31)) {
+            const uint32_t n = tok;
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64) sym[op + i] = literals[lp + i];
+            op += n;
+            lp += n;
+        } else {
+            const uint32_t len = ((tok >> 16) & 0xffu) + 3u;
+            const uint32_t dist = (tok & 0xffffu) + 1u;
+            const long long src = op - (long long)dist;
+            // everything this wave stored so far must be readable
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0);
+            uint16_t v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                v[k] = 0;
+                if (i < len) {
+                    const long long p = src + (long long)(dist < len ? i % dist : i);
+                    v[k] = p >= o0 ? sym[p] : (uint16_t)(256 + (p - ctx_base));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                if (i < len) sym[op + i] = v[k];
+            }
+            op += len;
+        }
+    }
+}
+
+// One workgroup; segment s (s >= 0) gets the last 32 KiB of its output finalised, in order.
+__global__ __launch_bounds__(1024)
+void inflate_context_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
+                            uint8_t *__restrict__ out) {
+    for (size_t s = 0; s + 1 < nsegs; ++s) {
+        const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
+        long long lo = o1 - kCtx;
+        if (lo < o0) lo = o0;
+        const long long ctx_base = o0 - kCtx;
+        for (long long i = lo + threadIdx.x; i < o1; i += blockDim.x) {
+            uint16_t v = sym[i];
+            if (v >= 256) v = out[ctx_base + (v - 256)];
+            out[i] = (uint8_t)v;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// grid.x = segment; bytes the context kernel already wrote are left alone
+__global__ __launch_bounds__(1024)
+void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
+                              uint8_t *__restrict__ out) {
+    const size_t s = blockIdx.x;
+    const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
+    long long hi = o1;
+    if (s + 1 < nsegs) {
+        hi = o1 - kCtx;
+        if (hi < o0) hi = o0;
+    }
+    const long long ctx_base = o0 - kCtx;
+    for (long long i = o0 + threadIdx.x; i < hi; i += blockDim.x) {
+        uint16_t v = sym[i];
+        if (v >= 256) v = out[ctx_base + (v - 256)];
+        out[i] = (uint8_t)v;
+    }
+}
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
+                                 size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
+                                 uint8_t *d_out, uint64_t out_len, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    (void)ntokens;
+    (void)nliterals;
+    if (out_len == 0 || nsegs == 0) return ZNG_ROCM_OK;
+    if (!d_tokens || !d_segs || !d_symbols || !d_out) return ZNG_ROCM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(inflate_segments_kernel, dim3((unsigned)((nsegs + 3) / 4)), dim3(256), 0, st, d_tokens,
+                       d_literals, d_segs, nsegs, d_symbols);
+    ZR_HIP(hipGetLastError());
+    if (nsegs > 1) {
+        hipLaunchKernelGGL(inflate_context_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, d_symbols, d_out);
+        ZR_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, d_symbols,
+                       d_out);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
+                         void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    zng_rocm_inflate_tokens tk;
+    int status = zng_rocm_inflate_tokens_decode(src, src_len, &tk);
+    if (out_len) *out_len = tk.out_len;
+    if (status == -4) {
+        zng_rocm_inflate_tokens_free(&tk);
+        return ZNG_ROCM_ENOMEM;
+    }
+    if (tk.out_len > dst_cap) {
+        set_error("inflate output (%llu bytes) exceeds dst_cap", (unsigned long long)tk.out_len);
+        zng_rocm_inflate_tokens_free(&tk);
+        return -5;
+    }
+    if (status < 0) set_error("%s", tk.msg);
+    int rc = ZNG_ROCM_OK;
+    if (tk.out_len) {
+        // one device allocation: tokens | segs | literals | symbols
+        const size_t tok_b = (tk.ntokens * 4 + 255) & ~(size_t)255;
+        const size_t seg_b = ((tk.nsegs + 1) * 24 + 255) & ~(size_t)255;
+        const size_t lit_b = (tk.nliterals + 255) & ~(size_t)255;
+        const size_t sym_b = (size_t)tk.out_len * 2;
+        uint8_t *d = nullptr;
+        if (hipMalloc(&d, tok_b + seg_b + lit_b + sym_b) != hipSuccess) {
+            zng_rocm_inflate_tokens_free(&tk);
+            set_error("device allocation for the token stream failed");
+            return ZNG_ROCM_ENOMEM;
+        }
+        hipError_t e = hipMemcpyAsync(d, tk.tokens, tk.ntokens * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + tok_b, tk.segs, (tk.nsegs + 1) * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && tk.nliterals)
+            e = hipMemcpyAsync(d + tok_b + seg_b, tk.literals, tk.nliterals, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            set_error("H2D of the token stream failed: %s", hipGetErrorString(e));
+            rc = ZNG_ROCM_EHIP;
+        } else {
+            rc = zng_rocm_inflate_resolve_dev((const uint32_t *)d, tk.ntokens, d + tok_b + seg_b, tk.nliterals,
+                                              (const uint64_t *)(d + tok_b), tk.nsegs,
+                                              (uint16_t *)(d + tok_b + seg_b + lit_b), d_dst, tk.out_len, st);
+        }
+        // the host buffers and the device workspace are released after the stream drained
+        if (hipStreamSynchronize(st) != hipSuccess && rc == ZNG_ROCM_OK) {
+            set_error("stream synchronize failed");
+            rc = ZNG_ROCM_EHIP;
+        }
+        (void)hipFree(d);
+    }
+    zng_rocm_inflate_tokens_free(&tk);
+    return rc != ZNG_ROCM_OK ? rc : status;
+}
+
+}  // extern "C"

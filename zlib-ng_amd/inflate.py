@@ -1,0 +1,80 @@
+"""Host mirror of the inflate path of include/zng_rocm.h (token decode on the host, copy
+resolution on the device).  Names follow the reference's API: `inflate_raw` is a one-shot
+`zng_inflate` of a raw (windowBits < 0) stream, Z_* codes as in zlib-ng.h.in:180-188."""
+import ctypes as C
+
+from . import rocm
+
+Z_OK, Z_STREAM_END, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR = 0, 1, -3, -4, -5
+
+
+class InflateTokens(C.Structure):
+    """zng_rocm_inflate_tokens"""
+    _fields_ = [
+        ("tokens", C.POINTER(C.c_uint32)), ("ntokens", C.c_size_t),
+        ("literals", C.POINTER(C.c_uint8)), ("nliterals", C.c_size_t),
+        ("segs", C.POINTER(C.c_uint64)), ("nsegs", C.c_size_t),
+        ("out_len", C.c_uint64), ("in_used", C.c_size_t),
+        ("status", C.c_int), ("msg", C.c_char_p),
+    ]
+
+
+class DecodedStream:
+    """numpy views of one decoded stream (copies; the C buffers are freed immediately)"""
+
+    def __init__(self, src):
+        import numpy as np
+        lib = rocm.lib()
+        raw = bytes(src)
+        buf = C.create_string_buffer(raw, max(len(raw), 1))
+        tk = InflateTokens()
+        self.status = lib.zng_rocm_inflate_tokens_decode(C.addressof(buf), len(raw), C.byref(tk))
+        self.msg = (tk.msg or b"").decode()
+        self.out_len = tk.out_len
+        self.in_used = tk.in_used
+        self.tokens = np.ctypeslib.as_array(tk.tokens, shape=(tk.ntokens,)).copy() if tk.ntokens else \
+            np.zeros(0, dtype=np.uint32)
+        self.literals = np.ctypeslib.as_array(tk.literals, shape=(tk.nliterals,)).copy() if tk.nliterals else \
+            np.zeros(0, dtype=np.uint8)
+        nseg = tk.nsegs
+        self.nsegs = nseg
+        self.segs = np.ctypeslib.as_array(tk.segs, shape=((nseg + 1) * 3,)).copy() if tk.segs else \
+            np.zeros(3, dtype=np.uint64)
+        lib.zng_rocm_inflate_tokens_free(C.byref(tk))
+
+
+def decode_tokens(src):
+    return DecodedStream(src)
+
+
+def resolve_dev(dec, stream=None):
+    """run the device stage on a DecodedStream; returns a uint8 CUDA tensor with the plaintext"""
+    import numpy as np
+    import torch
+    rocm._need_init()
+    n = int(dec.out_len)
+    out = torch.empty(max(n, 1), dtype=torch.uint8, device="cuda")
+    if n == 0:
+        return out[:0]
+    d_tok = torch.from_numpy(dec.tokens.view(np.int32)).cuda()
+    d_lit = torch.from_numpy(dec.literals).cuda() if dec.literals.size else torch.zeros(1, dtype=torch.uint8,
+                                                                                        device="cuda")
+    d_seg = torch.from_numpy(dec.segs.view(np.int64)).cuda()
+    d_sym = torch.empty(n, dtype=torch.int16, device="cuda")
+    rocm._check(rocm.lib().zng_rocm_inflate_resolve_dev(
+        rocm._dev_ptr(d_tok), dec.tokens.size, rocm._dev_ptr(d_lit), dec.literals.size, rocm._dev_ptr(d_seg),
+        dec.nsegs, rocm._dev_ptr(d_sym), rocm._dev_ptr(out), n, rocm._stream_ptr(stream)),
+        "zng_rocm_inflate_resolve_dev")
+    torch.cuda.current_stream().synchronize()
+    return out[:n]
+
+
+def inflate_raw(src, dst, stream=None):
+    """one-shot: host bytes in, plaintext into the CUDA tensor `dst`; returns (zlib status, bytes produced)"""
+    rocm._need_init()
+    raw = bytes(src)
+    buf = C.create_string_buffer(raw, max(len(raw), 1))
+    produced = C.c_uint64(0)
+    rc = rocm.lib().zng_rocm_inflate_raw(C.addressof(buf), len(raw), rocm._dev_ptr(dst), dst.numel(),
+                                         C.byref(produced), rocm._stream_ptr(stream))
+    return rc, produced.value

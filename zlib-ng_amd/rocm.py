@@ -60,6 +60,12 @@ _PROTOS = {
     "zng_rocm_chunkmemset_safe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]),
     "zng_rocm_chunksize": (C.c_uint32, []),
+    "zng_rocm_inflate_tokens_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zng_rocm_inflate_tokens_free": (None, [C.c_void_p]),
+    "zng_rocm_inflate_resolve_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "zng_rocm_inflate_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                       C.c_void_p]),
     "zng_rocm_trace_begin": (C.c_int, [C.c_int]),
     "zng_rocm_trace_end": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "zng_rocm_adler32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
