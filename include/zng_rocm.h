@@ -159,6 +159,25 @@ int zng_rocm_chunkmemset_safe_dev(uint8_t *d_base, const uint64_t *d_out_off, co
 /* slot `chunksize` (chunkset_tpl.h:9-11): store granule of the device copy kernels (bytes). */
 uint32_t zng_rocm_chunksize(void);
 
+/* ---- whole-stream deflate on device, many independent streams (level-1 class) -------------
+ * The caller this replaces is deflate_quick (deflate_quick.c:47-130) behind DEFLATE_HOOK
+ * (deflate.c:1039): one raw RFC 1951 stream per job, a single final static-Huffman block, built
+ * from the same primitives (insert_string hash, single chain-head probe, compare256, static trees)
+ * run wavefront-wide with the head table in LDS.  Output is valid deflate that any inflater
+ * restores to the input; it is not bit-identical to the reference's stream.
+ *   in:  device, 16-byte aligned, readable up to the next 16-byte boundary past in_len
+ *   out: device, 4-byte aligned, out_cap >= zng_rocm_deflate_quick_bound(in_len)
+ * `jobs` is a HOST array (copied internally).  d_results (device) receives per job
+ * {compressed length, adler32(1, in, in_len)} -- the {clen, check} row of the multi-stream table. */
+typedef struct zng_rocm_stream_job {
+    const uint8_t *in;
+    uint8_t       *out;
+    uint32_t       in_len;
+    uint32_t       out_cap;
+} zng_rocm_stream_job;
+size_t zng_rocm_deflate_quick_bound(size_t source_len);
+int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, uint32_t *d_results, void *stream);
+
 /* ---- inflate: host bitstream decode -> token stream -> device copy resolution -------------
  * The split of slot `inflate_fast` (inffast_tpl.h:53-318): the sequential Huffman decode loop
  * (:151-226) runs on the host and emits TOKENS instead of stores; the literal stores and match

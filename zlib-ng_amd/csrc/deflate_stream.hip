@@ -1,0 +1,417 @@
+// deflate_stream.hip -- whole-stream deflate on device for MANY independent streams (pigz-style),
+// level-1 class: the caller is zlib-ng's deflate_quick (deflate_quick.c:47-130), reached through
+// DEFLATE_HOOK (deflate.c:1039).  Same building blocks -- quick_insert_string's hash
+// (insert_string.c:11-13), a single chain-head probe, compare256, static Huffman trees
+// (zng_tr_emit_lit / zng_tr_emit_dist, trees_emit.h:102-164; RFC 1951 3.2.6) -- re-laid-out for wave64:
+//
+//   K1 lz_quick_kernel   one 256-lane workgroup per stream.  256 consecutive positions per step:
+//        wavefront-wide insert_string (all 256 hashes at once; a position sees earlier positions of
+//        the same step exactly as the sequential loop of insert_string_tpl.h:85-104 would), the head
+//        table (2^15 x u16) lives in LDS and is slid with slide_hash's saturating subtract
+//        (slide_hash_c.c:15-52) every 32 KiB, per-lane probe compare, then a greedy parse in
+//        lane order (readlane), long matches extended with the wavefront-wide compare256.
+//        Output: one 32-bit selector per input position (skip / literal / match{len,dist}).
+//   K2 emit_static_kernel one workgroup per stream: static-Huffman code per selector, bit offsets by
+//        a block scan, bits assembled in an LDS tile with ds_or and streamed out with plain stores;
+//        also Adler-32 of the input (the {clen, check, ulen} row of SURVEY.md section 8e).
+//
+// The output is ONE final static block per stream (what deflate_quick emits for a Z_FINISH call),
+// valid RFC 1951; it is not bit-identical to the reference's (every position is inserted into the
+// hash, 15-bit table), which the reference's own test strategy never requires.
+#include "context.h"
+#include "deflate_dev.h"
+
+#include <vector>
+
+namespace zr {
+
+constexpr int      kQHashBits = 15;
+constexpr uint32_t kQMaxDist = 32768u - kMinLookahead;     // MAX_DIST(s), deflate.h:410-415
+constexpr uint32_t kProbe = 32;                            // bytes compared per lane before the parse
+constexpr uint32_t kWantMinMatch = 4;                      // WANT_MIN_MATCH, deflate.h
+
+struct StreamJobDev {
+    const uint8_t *in;
+    uint8_t       *out;
+    uint32_t       in_len;
+    uint32_t       out_cap;
+    uint64_t       sel_off;      // first selector of this stream in the workspace
+};
+
+__device__ __forceinline__ uint32_t hash15(uint32_t val) { return (val * 2654435761u) >> (32 - kQHashBits); }
+
+// bounded wave-wide compare: number of equal leading bytes of a[0..rem) and b[0..rem), rem <= 256
+__device__ __forceinline__ uint32_t compare_wave_bounded(const uint8_t *a, const uint8_t *b, uint32_t rem, int lane) {
+    const uint32_t off = 4u * (uint32_t)lane;
+    uint32_t x = 0;
+    if (off + 4 <= rem) {
+        x = load_u32(a + off) ^ load_u32(b + off);
+    } else if (off < rem) {
+        for (uint32_t j = 0; off + j < rem; ++j) x |= (uint32_t)(a[off + j] ^ b[off + j]) << (8 * j);
+    }
+    const unsigned long long diff = __ballot(x != 0);
+    if (diff == 0) return rem;
+    const int first = __ffsll((long long)diff) - 1;
+    const uint32_t d = (uint32_t)__shfl((int)x, first, 64);
+    const uint32_t n = (uint32_t)first * 4u + ((uint32_t)(__ffs((int)d) - 1) >> 3);
+    return n < rem ? n : rem;
+}
+
+__global__ __launch_bounds__(256)
+void lz_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
+    __shared__ uint16_t head[1 << kQHashBits];
+    __shared__ uint32_t sh_next;                     // next position the parse will visit
+
+    const StreamJobDev job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t n = job.in_len;
+    uint32_t *sel = sel_base + job.sel_off;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int i = t; i < (1 << kQHashBits) / 2; i += 256) reinterpret_cast<uint32_t *>(head)[i] = 0;
+    if (t == 0) sh_next = 0;
+    __syncthreads();
+
+    uint32_t wb = 0;                                 // window base: head entries are (position - wb), 0 = empty
+    for (uint32_t P = 0; P < n; P += 256) {
+        if (P + 256u - wb > 65535u) {
+            // slide_hash: entries move down by one window (32 KiB), saturating at 0
+            for (int i = t; i < (1 << kQHashBits) / 2; i += 256) {
+                uint32_t two = reinterpret_cast<uint32_t *>(head)[i];
+                uint32_t lo = two & 0xffffu, hi = two >> 16;
+                lo = lo >= 32768u ? lo - 32768u : 0u;
+                hi = hi >= 32768u ? hi - 32768u : 0u;
+                reinterpret_cast<uint32_t *>(head)[i] = lo | (hi << 16);
+            }
+            wb += 32768u;
+            __syncthreads();
+        }
+        const uint32_t p = P + (uint32_t)t;
+        const bool can = p + kWantMinMatch <= n;       // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
+        const uint32_t val = can ? load_u32(in + p) : 0u;
+        const uint32_t h = can ? hash15(val) : 0xffffffffu;
+
+        // wavefront-wide insert_string, part 1: order among the 64 positions of this wave
+        int before = -1;
+        bool later = false;
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t hj = (uint32_t)__shfl((int)h, j, 64);
+            const bool same = can && hj == h;
+            if (same && j < lane) before = j;
+            if (same && j > lane) later = true;
+        }
+        // part 2: the four waves touch the table in position order
+        uint32_t cand0 = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && can) {
+                cand0 = head[h];
+                if (!later) head[h] = (uint16_t)(p - wb);
+            }
+            __syncthreads();
+        }
+        uint32_t c = 0xffffffffu;
+        if (can) {
+            if (before >= 0) c = P + (uint32_t)(wave * 64 + before);
+            else if (cand0) c = wb + cand0;
+        }
+
+        // per-lane probe compare (first kProbe bytes)
+        uint32_t len = 0, dist = 0;
+        if (c != 0xffffffffu && c < p && p - c <= kQMaxDist && load_u32(in + c) == val) {
+            const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
+            len = 4;
+            while (len < kProbe) {
+                if (len + 4 <= maxlen) {
+                    const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
+                    if (x) {
+                        len += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                        break;
+                    }
+                    len += 4;
+                } else {
+                    while (len < maxlen && in[p + len] == in[c + len]) ++len;
+                    break;
+                }
+            }
+            dist = p - c;
+        }
+
+        // greedy parse in position order; a wave continues where the previous one stopped
+        unsigned long long visited = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+                const uint32_t w0 = P + 64u * (uint32_t)w;
+                uint32_t nxt = sh_next;
+                uint32_t pos = nxt > w0 ? nxt - w0 : 0u;
+                while (pos < 64u && w0 + pos < n) {
+                    uint32_t L = (uint32_t)__shfl((int)len, (int)pos, 64);
+                    if (L >= kWantMinMatch) {
+                        const uint32_t pabs = w0 + pos;
+                        const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
+                        if (L >= kProbe && L < maxlen) {
+                            const uint32_t D = (uint32_t)__shfl((int)dist, (int)pos, 64);
+                            uint32_t rem = maxlen - L;
+                            if (rem > 256u) rem = 256u;
+                            L += compare_wave_bounded(in + pabs + L, in + pabs - D + L, rem, lane);
+                            if ((uint32_t)lane == pos) len = L;
+                        }
+                        visited |= 1ull << pos;
+                        pos += L;
+                    } else {
+                        visited |= 1ull << pos;
+                        pos += 1;
+                    }
+                }
+                if (lane == 0) sh_next = w0 + pos > nxt ? w0 + pos : nxt;
+            }
+            __syncthreads();
+        }
+        if (p < n) {
+            uint32_t s = 0;
+            if ((visited >> lane) & 1ull)
+                s = len >= kWantMinMatch ? (0x80000000u | ((len - 3u) << 16) | (dist - 1u)) : 0x40000000u;
+            sel[p] = s;
+        }
+    }
+}
+
+// ---- static Huffman (RFC 1951 3.2.6; the reference's static_ltree / static_dtree, trees_tbl.h) -----------
+__device__ __forceinline__ uint32_t rev_bits(uint32_t code, uint32_t n) { return __brev(code) >> (32 - n); }
+
+__device__ __forceinline__ void static_literal(uint32_t b, uint32_t &bits, uint32_t &nb) {
+    if (b < 144) { bits = rev_bits(0x30 + b, 8); nb = 8; }
+    else         { bits = rev_bits(0x190 + (b - 144), 9); nb = 9; }
+}
+
+__device__ __forceinline__ void static_match(uint32_t len, uint32_t dist, uint32_t &bits, uint32_t &nb) {
+    // length symbol 257..285 with extra bits (RFC 1951 3.2.5; base_length/extra_lbits of trees_tbl.h)
+    const uint32_t l = len - 3;
+    uint32_t sym, eb = 0, ev = 0;
+    if (l < 8) sym = 257 + l;
+    else if (l == 255) sym = 285;
+    else {
+        const uint32_t lg = 31u - (uint32_t)__clz((int)l);          // 3..7
+        eb = lg - 2;
+        sym = 257 + 4 * eb + 4 + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1u);
+    }
+    uint32_t code, cn;
+    if (sym < 280) { code = rev_bits(sym - 256, 7); cn = 7; }
+    else           { code = rev_bits(0xC0 + (sym - 280), 8); cn = 8; }
+    bits = code | (ev << cn);
+    nb = cn + eb;
+    // distance code 0..29, 5-bit static code, extra bits
+    const uint32_t x = dist - 1;
+    uint32_t dc, deb = 0, dev = 0;
+    if (x < 4) dc = x;
+    else {
+        const uint32_t lg = 31u - (uint32_t)__clz((int)x);          // 2..14
+        deb = lg - 1;
+        dc = 2 * lg + ((x >> deb) & 1u);
+        dev = x & ((1u << deb) - 1u);
+    }
+    bits |= rev_bits(dc, 5) << nb;
+    nb += 5;
+    bits |= dev << nb;
+    nb += deb;
+}
+
+constexpr int kEmitPer = 16;                 // positions per lane per tile
+constexpr int kEmitTile = 256 * kEmitPer;    // 4096 positions
+constexpr int kEmitWords = kEmitTile + 8;    // worst case 31 bits per position < 1 word each
+
+__global__ __launch_bounds__(256)
+void emit_static_kernel(const StreamJobDev *__restrict__ jobs, const uint32_t *__restrict__ sel_base,
+                        uint32_t *__restrict__ results) {
+    __shared__ uint32_t obuf[kEmitWords];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long red_a[4], red_b[4];
+
+    const StreamJobDev job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t n = job.in_len;
+    const uint32_t *sel = sel_base + job.sel_off;
+    uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    uint32_t wbase = 0;          // whole words already written
+    uint32_t cw = 3u, cbits = 3; // carry word: block header BFINAL=1, BTYPE=01 (deflate_quick.c:30-34)
+    unsigned long long accA = 0, accB = 0;
+
+    for (uint32_t base = 0; base < n; base += kEmitTile) {
+        const uint32_t p0 = base + (uint32_t)t * kEmitPer;
+        uint32_t code[kEmitPer], nbv[kEmitPer];
+        uint32_t mine = 0;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (p0 < n) {
+            raw = *reinterpret_cast<const uint4 *>(in + p0);      // streams are 16-byte aligned and padded
+            const uint32_t valid = n - p0;
+            if (valid < 16) {
+                uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+                for (int i = 0; i < 4; ++i) {
+                    const int keep = (int)valid - 4 * i;
+                    if (keep <= 0) w[i] = 0;
+                    else if (keep < 4) w[i] &= (1u << (8 * keep)) - 1u;
+                }
+                raw = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // Adler-32 of the input, linear form: B += (n - pos) * byte
+            uint32_t a = __builtin_amdgcn_sad_u8(raw.x, 0u, 0u);
+            a = __builtin_amdgcn_sad_u8(raw.y, 0u, a);
+            a = __builtin_amdgcn_sad_u8(raw.z, 0u, a);
+            a = __builtin_amdgcn_sad_u8(raw.w, 0u, a);
+            uint32_t wsum = __builtin_amdgcn_udot4(raw.x, 0x0D0E0F10u, 0u, false);
+            wsum = __builtin_amdgcn_udot4(raw.y, 0x090A0B0Cu, wsum, false);
+            wsum = __builtin_amdgcn_udot4(raw.z, 0x05060708u, wsum, false);
+            wsum = __builtin_amdgcn_udot4(raw.w, 0x01020304u, wsum, false);
+            const long long lead = (long long)n - (long long)p0 - 16;     // may be negative on the last piece
+            const long long term = lead * (long long)a + (long long)wsum; // >= 0 as a whole
+            accB = (accB + (unsigned long long)term) % kAdlerBase;
+            accA += a;
+        }
+        const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < kEmitPer; ++j) {
+            const uint32_t p = p0 + (uint32_t)j;
+            uint32_t s = p < n ? sel[p] : 0u;
+            code[j] = 0;
+            nbv[j] = 0;
+            if (s & 0x80000000u) static_match(((s >> 16) & 0xffu) + 3u, (s & 0xffffu) + 1u, code[j], nbv[j]);
+            else if (s & 0x40000000u) static_literal((rw[j >> 2] >> (8 * (j & 3))) & 0xffu, code[j], nbv[j]);
+            mine += nbv[j];
+        }
+        // block exclusive scan of `mine`
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        for (int i = t; i < kEmitWords; i += 256) obuf[i] = 0;
+        __syncthreads();
+        uint32_t wave_off = 0, tile_bits = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wave_off += wave_tot[w];
+            tile_bits += wave_tot[w];
+        }
+        if (t == 0) obuf[0] = cw;
+        __syncthreads();
+        uint32_t cur = cbits + wave_off + incl - mine;
+#pragma unroll
+        for (int j = 0; j < kEmitPer; ++j) {
+            if (nbv[j]) {
+                const uint32_t word = cur >> 5, sh = cur & 31u;
+                atomicOr(&obuf[word], code[j] << sh);
+                if (sh + nbv[j] > 32u) atomicOr(&obuf[word + 1], code[j] >> (32u - sh));
+                cur += nbv[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t total = cbits + tile_bits;
+        const uint32_t full = total >> 5;
+        for (uint32_t i = (uint32_t)t; i < full; i += 256) outw[wbase + i] = obuf[i];
+        const uint32_t next_cw = obuf[full];
+        __syncthreads();
+        wbase += full;
+        cw = next_cw;
+        cbits = total & 31u;
+    }
+
+    // end-of-block code 256 = seven 0 bits (zng_emit_end_block, trees_emit.h:169-180), then pad to a byte
+    cbits += 7;
+    // reductions for Adler
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        accA += __shfl_xor(accA, m, 64);
+        accB += __shfl_xor(accB, m, 64);
+    }
+    if (lane == 0) {
+        red_a[wave] = accA;
+        red_b[wave] = accB;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint8_t *outb = job.out;
+        if (cbits >= 32) {
+            outw[wbase++] = cw;
+            cw = 0;
+            cbits -= 32;
+        }
+        uint32_t bytes = wbase * 4u;
+        for (uint32_t k = 0; k < (cbits + 7u) / 8u; ++k) outb[bytes++] = (uint8_t)(cw >> (8 * k));
+        const unsigned long long A = (red_a[0] + red_a[1] + red_a[2] + red_a[3]) % kAdlerBase;
+        const unsigned long long B = (red_b[0] + red_b[1] + red_b[2] + red_b[3]) % kAdlerBase;
+        results[2 * blockIdx.x] = bytes;
+        results[2 * blockIdx.x + 1] = (uint32_t)(((1 + A) % kAdlerBase) | ((((unsigned long long)n + B) % kAdlerBase) << 16));
+    }
+}
+
+struct DeflateScratch {
+    StreamJobDev *d_jobs = nullptr;
+    std::vector<StreamJobDev> h_jobs; // pageable on purpose: hipMemcpyAsync stages it before returning
+    size_t        job_cap = 0;
+    uint32_t     *d_sel = nullptr;
+    size_t        sel_cap = 0;
+};
+static DeflateScratch g_ds;
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+size_t zng_rocm_deflate_quick_bound(size_t source_len) {
+    // 3 header bits + at most 9 bits per input byte (a match of >= 4 bytes costs <= 31 bits) + 7 EOB bits,
+    // cf. DEFLATE_QUICK_OVERHEAD / DEFLATE_BLOCK_OVERHEAD (zutil.h:71-79, deflate.c:773-777); rounded so that
+    // consecutive streams stay 16-byte aligned.
+    size_t b = source_len + ((source_len + 7) >> 3) + 8;
+    return (b + 15) & ~(size_t)15;
+}
+
+int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, uint32_t *d_results, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!njobs) return ZNG_ROCM_OK;
+    if (!jobs || !d_results) return ZNG_ROCM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (njobs > g_ds.job_cap) {
+        if (g_ds.d_jobs) (void)hipFree(g_ds.d_jobs);
+        g_ds.job_cap = 0;
+        ZR_HIP(hipMalloc(&g_ds.d_jobs, njobs * sizeof(StreamJobDev)));
+        g_ds.job_cap = njobs;
+    }
+    g_ds.h_jobs.resize(njobs);
+    uint64_t total = 0;
+    for (size_t i = 0; i < njobs; ++i) {
+        const zng_rocm_stream_job &j = jobs[i];
+        if ((j.in_len && (!j.in || !j.out)) || ((uintptr_t)j.in & 15) || ((uintptr_t)j.out & 3) ||
+            j.out_cap < zng_rocm_deflate_quick_bound(j.in_len)) {
+            set_error("job %zu: streams must be 16-byte aligned (in), 4-byte aligned (out) and out_cap >= "
+                      "zng_rocm_deflate_quick_bound(in_len)", i);
+            return ZNG_ROCM_EINVAL;
+        }
+        g_ds.h_jobs[i] = StreamJobDev{j.in, j.out, j.in_len, j.out_cap, total};
+        total += j.in_len;
+    }
+    if (total > g_ds.sel_cap) {
+        if (g_ds.d_sel) (void)hipFree(g_ds.d_sel);
+        g_ds.sel_cap = 0;
+        ZR_HIP(hipMalloc(&g_ds.d_sel, (total + 1024) * sizeof(uint32_t)));
+        g_ds.sel_cap = total + 1024;
+    }
+    ZR_HIP(hipMemcpyAsync(g_ds.d_jobs, g_ds.h_jobs.data(), njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
+    trace_mark(st, true);
+    hipLaunchKernelGGL(lz_quick_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
+    trace_mark(st, false);
+    ZR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel,
+                       d_results);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Host mirror of the multi-stream deflate path of include/zng_rocm.h.
+
+`deflate_quick_batch` compresses many independent streams (pigz-style, BASELINE.json configs[4]) that are
+already resident in HBM; names follow the reference (`deflateBound`-style bound, level-1 = deflate_quick,
+deflate.c:142-168)."""
+import ctypes as C
+
+from . import rocm
+
+
+class StreamJob(C.Structure):
+    """zng_rocm_stream_job"""
+    _fields_ = [("in_ptr", C.c_void_p), ("out_ptr", C.c_void_p), ("in_len", C.c_uint32), ("out_cap", C.c_uint32)]
+
+
+def deflate_quick_bound(n):
+    return rocm.lib().zng_rocm_deflate_quick_bound(n)
+
+
+class QuickBatch:
+    """A fixed set of streams laid out in two device tensors.
+
+    src:  uint8 CUDA tensor holding the streams; stream i = src[in_off[i] : in_off[i] + in_len[i]],
+          every in_off a multiple of 16 and the tensor padded to a multiple of 16.
+    The compressed streams land in `dst` at out_off[i] (bound-sized slots); `results` is an int32
+    CUDA tensor [n, 2] = {compressed length, adler32 of the input}.
+    """
+
+    def __init__(self, src, in_off, in_len):
+        import torch
+        rocm._need_init()
+        self.src = src
+        self.n = len(in_len)
+        self.in_off = [int(v) for v in in_off]
+        self.in_len = [int(v) for v in in_len]
+        self.bounds = [deflate_quick_bound(v) for v in self.in_len]
+        self.out_off = [0] * self.n
+        total = 0
+        for i, b in enumerate(self.bounds):
+            self.out_off[i] = total
+            total += b
+        self.dst = torch.empty(max(total, 16), dtype=torch.uint8, device=src.device)
+        self.results = torch.zeros((self.n, 2), dtype=torch.int32, device=src.device)
+        jobs = (StreamJob * self.n)()
+        base_in, base_out = src.data_ptr(), self.dst.data_ptr()
+        for i in range(self.n):
+            if self.in_off[i] % 16:
+                raise ValueError("stream offsets must be multiples of 16")
+            jobs[i].in_ptr = base_in + self.in_off[i]
+            jobs[i].out_ptr = base_out + self.out_off[i]
+            jobs[i].in_len = self.in_len[i]
+            jobs[i].out_cap = self.bounds[i]
+        self.jobs = jobs
+
+    def run(self, stream=None):
+        """asynchronous on `stream`: K1 match/parse + K2 static-Huffman emit for every stream"""
+        rocm._check(rocm.lib().zng_rocm_deflate_quick_dev(C.byref(self.jobs), self.n, rocm._dev_ptr(self.results),
+                                                          rocm._stream_ptr(stream)), "zng_rocm_deflate_quick_dev")
+
+    def compressed(self, i, results_host=None):
+        """bytes of stream i (synchronises)"""
+        res = self.results.cpu() if results_host is None else results_host
+        clen = int(res[i, 0])
+        o = self.out_off[i]
+        return self.dst[o:o + clen].cpu().numpy().tobytes()
