@@ -1,0 +1,95 @@
+"""GPU: multi-stream deflate (level-1 class, static Huffman) -- every stream must be a valid raw RFC 1951
+stream that (a) CPython's zlib, (b) the oracle inflater and (c) the product's own inflate path restore to
+the input bit-exactly; Adler-32 row must equal the oracle's.  Compressed bytes are not compared with the
+reference's (its tests never do)."""
+import importlib
+import zlib
+
+import numpy as np
+import pytest
+
+import inflate_util
+import synth
+from gpu_common import product, torch_mod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    zr = product()
+    zr.init()
+    return zr, importlib.import_module("zlib-ng_amd.deflate"), importlib.import_module("zlib-ng_amd.inflate")
+
+
+def _pack(streams):
+    """concatenate streams at 16-byte aligned offsets"""
+    offs, lens, chunks, pos = [], [], [], 0
+    for s in streams:
+        offs.append(pos)
+        lens.append(len(s))
+        pad = (-len(s)) % 16
+        chunks.append(s + b"\0" * pad)
+        pos += len(s) + pad
+    blob = b"".join(chunks) + b"\0" * 16
+    return np.frombuffer(blob, dtype=np.uint8).copy(), offs, lens
+
+
+def _streams():
+    rng = np.random.default_rng(17)
+    mix = synth.silesia_like(6 << 20, seed=99, seg_bytes=1 << 20).tobytes()
+    out = [mix[i << 20:(i + 1) << 20] for i in range(6)]                  # one per class, 1 MiB each
+    out += [b"", b"a", b"ab", b"abc", b"abcd", b"abcde", b"aaaa", b"a" * 5, b"a" * 257, b"a" * 258, b"a" * 259,
+            b"a" * 100000, b"ab" * 50000, bytes(range(256)) * 300, b"x" * 255 + b"y",
+            rng.integers(0, 256, size=70001, dtype=np.uint8).tobytes(),
+            (rng.integers(0, 256, size=32768, dtype=np.uint8).tobytes()) * 3,   # distance exactly 32768: too far
+            (rng.integers(0, 256, size=32506, dtype=np.uint8).tobytes()) * 3,   # distance == MAX_DIST
+            mix[:65535], mix[:65536], mix[:65537], mix[100:100 + 255], mix[:4096 + 3]]
+    return out
+
+
+def test_round_trip_every_stream(mods, oracle):
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    streams = _streams()
+    blob, offs, lens = _pack(streams)
+    src = torch.from_numpy(blob).cuda()
+    batch = dfl.QuickBatch(src, offs, lens)
+    batch.run()
+    torch.cuda.synchronize()
+    res = batch.results.cpu()
+    for i, s in enumerate(streams):
+        comp = batch.compressed(i, res)
+        assert len(comp) <= batch.bounds[i]
+        assert zlib.decompressobj(-15).decompress(comp) == s, i                      # independent inflater
+        st, msg, out, used = inflate_util.oracle_inflate(comp, cap=len(s) + 16)      # oracle
+        assert st == 1 and out == s and used == len(comp), (i, st, msg)
+        dec = inf.decode_tokens(comp)                                                 # product's own inflate path
+        assert dec.status == 1
+        assert inf.resolve_dev(dec).cpu().numpy().tobytes() == s
+        want_adler = zlib.adler32(s)
+        assert (int(res[i, 1]) & 0xffffffff) == want_adler, i
+        if len(s):
+            buf = np.frombuffer(s, dtype=np.uint8)
+            assert want_adler == oracle.oracle_adler32(1, buf.ctypes.data, len(s))
+    # level-1 class ratio sanity on the six-class mix (reference level 1 on text-like data: ~1.9)
+    mix_in = sum(lens[:6])
+    mix_out = sum(int(res[i, 0]) for i in range(6))
+    assert mix_in / mix_out > 1.5, mix_in / mix_out
+
+
+def test_many_equal_streams_and_rerun(mods):
+    """cfg5 shape in small: 64 x 256 KiB slices, run twice on the same batch (buffers are reused)"""
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    data = synth.silesia_like(16 << 20, seed=0x5EED0005, seg_bytes=1 << 20)
+    n, each = 64, 256 << 10
+    src = torch.from_numpy(data).cuda()
+    batch = dfl.QuickBatch(src, [i * each for i in range(n)], [each] * n)
+    for _ in range(2):
+        batch.run()
+    torch.cuda.synchronize()
+    res = batch.results.cpu()
+    raw = data.tobytes()
+    for i in range(n):
+        assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == raw[i * each:(i + 1) * each]
