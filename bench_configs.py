@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench_configs.py -- measures every BASELINE.json config on ONE MI355X and prints one JSON document.
+
+bench.py stays the driver's contract (configs[1], one line); this script is the wider report DESIGN.md
+quotes: per config the device-resident rate, the PCIe-inclusive rate where a host buffer is handed over,
+parity checks, and a CPU figure beside it (the oracle / oracle/_ref for checksums; CPython's zlib -- classic
+zlib 1.2.11, an independent codec, NOT the reference -- for deflate/inflate, since zlib-ng itself cannot be
+built under the round rules).
+
+  python bench_configs.py [--quick] [--only cfg5]
+"""
+import argparse
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def gpu_time_ms(fn, reps, torch):
+    fn()
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        t.append(a.elapsed_time(b))
+    return statistics.median(t)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="smaller sizes (smoke)")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import oracle_lib
+    import synth
+    zr = importlib.import_module("zlib-ng_amd")
+    dfl = importlib.import_module("zlib-ng_amd.deflate")
+    inf = importlib.import_module("zlib-ng_amd.inflate")
+    zr.init(0)
+    orc = oracle_lib.load()
+    ref_crc = oracle_lib.load_ref_crc32()
+    report = {"device": torch.cuda.get_device_name(0), "host_cpus": os.cpu_count()}
+    want = lambda name: not args.only or args.only == name
+
+    # ---- cfg1: zng_adler32 over 64 MiB, CPU plumbing + bit-exact check --------------------------------
+    if want("cfg1"):
+        n = 64 << 20
+        host = np.frombuffer(os.urandom(n), dtype=np.uint8)
+        t0 = time.perf_counter()
+        cpu = orc.oracle_adler32(1, host.ctypes.data, n)
+        t_cpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        slot = zr.adler32_z(1, host)                         # host pointer in, PCIe staging inside
+        t_slot = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        slot = zr.adler32_z(1, host)
+        t_slot = min(t_slot, time.perf_counter() - t0)
+        dev = torch.from_numpy(host).cuda()
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ms = gpu_time_ms(lambda: zr.adler32_dev(dev, out), 20, torch)
+        report["cfg1"] = {
+            "workload": "zng_adler32 over 64 MiB /dev/urandom", "bit_exact": slot == cpu == (out[0].item() & 0xffffffff),
+            "cpu_oracle_GBps": round(n / 1e9 / t_cpu, 2), "slot_host_pointer_GBps_pcie_inclusive": round(n / 1e9 / t_slot, 2),
+            "device_resident_GBps": round(n / 1e9 / (ms / 1e3), 1), "device_ms": round(ms, 4)}
+
+    # ---- cfg2 sizes: device-resident checksum kernels at 64 MiB / 256 MiB / 1 GiB ----------------------
+    if want("cfg2"):
+        rows = []
+        sizes = [64, 256] if args.quick else [64, 256, 1024]
+        big = torch.randint(0, 256, ((max(sizes) << 20) + 16,), dtype=torch.uint8, device="cuda")
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        dst = torch.empty_like(big)
+        for mib in sizes:
+            n = mib << 20
+            row = {"MiB": mib}
+            for name, fn, traffic in (
+                    ("adler32", lambda: zr.adler32_dev(big, out, length=n), 1),
+                    ("crc32", lambda: zr.crc32_dev(big, out, length=n), 1),
+                    ("adler32+crc32 fused", lambda: zr.adler32_crc32_dev(big, out, length=n), 1),
+                    ("fold_copy (adler+crc, 2N traffic)", lambda: zr.fold_copy_dev(3, dst, big, out, length=n), 2)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                zr.trace_begin(20)
+                for _ in range(20):
+                    fn()
+                ms = statistics.mean(zr.trace_end(20))
+                step = gpu_time_ms(fn, 10, torch)
+                row[name] = {"kernel_ms": round(ms, 4), "algorithmic_GBps": round(traffic * n / 1e9 / (ms / 1e3), 1),
+                             "frac_of_8TBps": round(traffic * n / 1e9 / (ms / 1e3) / 8000, 3),
+                             "step_ms_incl_finalize": round(step, 4)}
+            rows.append(row)
+        report["cfg2"] = rows
+        del big, dst
+
+    # ---- cfg3: raw inflate of a level-6 stream ----------------------------------------------------------
+    if want("cfg3"):
+        n = (32 if args.quick else 256) << 20
+        plain = synth.silesia_like(n, seed=0x5EED0003)
+        t0 = time.perf_counter()
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(plain.tobytes()) + c.flush()
+        t_comp = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        back = zlib.decompressobj(-15).decompress(comp)
+        t_pyinf = time.perf_counter() - t0
+        assert back == plain.tobytes()
+        del back
+        t0 = time.perf_counter()
+        dec = inf.decode_tokens(comp)
+        t_dec = time.perf_counter() - t0
+        assert dec.status == 1
+        d_tok = torch.from_numpy(dec.tokens.view(np.int32)).cuda()
+        d_lit = torch.from_numpy(dec.literals).cuda()
+        d_seg = torch.from_numpy(dec.segs.view(np.int64)).cuda()
+        d_sym = torch.empty(n, dtype=torch.int16, device="cuda")
+        d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rocm = zr.rocm
+
+        def resolve():
+            rocm._check(rocm.lib().zng_rocm_inflate_resolve_dev(
+                rocm._dev_ptr(d_tok), dec.tokens.size, rocm._dev_ptr(d_lit), dec.literals.size, rocm._dev_ptr(d_seg),
+                dec.nsegs, rocm._dev_ptr(d_sym), rocm._dev_ptr(d_out), n, rocm._stream_ptr(None)), "resolve")
+        ms = gpu_time_ms(resolve, 5, torch)
+        ok = torch.equal(d_out, torch.from_numpy(plain).cuda())
+        t0 = time.perf_counter()
+        dst = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rc, produced = inf.inflate_raw(comp, dst)
+        torch.cuda.synchronize()
+        t_e2e = time.perf_counter() - t0
+        report["cfg3"] = {
+            "workload": "raw inflate of a level-6 stream (CPython zlib encoder), %d MiB plaintext, Silesia-like mix" % (n >> 20),
+            "compressed_MiB": round(len(comp) / 2**20, 2), "ratio": round(n / len(comp), 3), "bit_exact": bool(ok and rc == 1),
+            "tokens": int(dec.tokens.size), "literal_bytes": int(dec.literals.size), "segments": int(dec.nsegs),
+            "host_decode_s": round(t_dec, 3), "host_decode_out_MBps": round(n / 1e6 / t_dec, 1),
+            "device_resolve_ms": round(ms, 3), "device_resolve_out_GBps": round(n / 1e9 / (ms / 1e3), 2),
+            "device_algorithmic_GBps_C_plus_U": round((n + len(comp)) / 1e9 / (ms / 1e3), 2),
+            "end_to_end_s_host_stream_to_device_plaintext": round(t_e2e, 3),
+            "end_to_end_out_MBps": round(n / 1e6 / t_e2e, 1), "end_to_end_in_MBps": round(len(comp) / 1e6 / t_e2e, 1),
+            "cpu_python_zlib_inflate_out_MBps_1thread": round(n / 1e6 / t_pyinf, 1),
+            "cpu_python_zlib_deflate6_in_MBps_1thread": round(n / 1e6 / t_comp, 1)}
+        del d_tok, d_lit, d_seg, d_sym, d_out, dst
+
+    # ---- cfg5: 4096 independent 1 MiB streams, level-1 class, one GPU's view ----------------------------
+    if want("cfg5"):
+        nstreams = 256 if args.quick else 4096
+        each = 1 << 20
+        base = synth.silesia_like(96 << 20, seed=0x5EED0005, seg_bytes=1 << 20)     # 96 distinct 1 MiB slices
+        host = np.concatenate([base] * ((nstreams * each + base.size - 1) // base.size))[:nstreams * each]
+        src = torch.from_numpy(host).cuda()
+        batch = dfl.QuickBatch(src, [i * each for i in range(nstreams)], [each] * nstreams)
+        ms = gpu_time_ms(batch.run, 3, torch)
+        zr.trace_begin(4)
+        batch.run()
+        k1 = zr.trace_end(4)
+        res = batch.results.cpu()
+        clen = int(res[:, 0].sum())
+        sample = [0, 1, 5, 17, nstreams - 1]
+        ok = all(zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == host[i * each:(i + 1) * each].tobytes()
+                 for i in sample)
+        ok = ok and all((int(res[i, 1]) & 0xffffffff) == zlib.adler32(host[i * each:(i + 1) * each].tobytes()) for i in sample)
+        t0 = time.perf_counter()
+        cl1 = 0
+        for i in range(16):
+            cl1 += len(zlib.compress(host[i * each:(i + 1) * each].tobytes(), 1))
+        t_cpu = time.perf_counter() - t0
+        report["cfg5"] = {
+            "workload": "%d independent 1 MiB streams, level-1 class (static Huffman), one GPU" % nstreams,
+            "round_trip_sample_ok": bool(ok), "ratio": round(nstreams * each / clen, 3),
+            "step_ms": round(ms, 2), "input_GBps": round(nstreams * each / 1e9 / (ms / 1e3), 2),
+            "lz_kernel_ms": round(k1[0], 2) if k1 else None,
+            "cpu_python_zlib_level1_in_MBps_1thread": round(16 * each / 1e6 / t_cpu, 1),
+            "cpu_python_zlib_level1_ratio": round(16 * each / cl1, 3)}
+
+    print(json.dumps(report, indent=1))
+
+
+if __name__ == "__main__":
+    main()
