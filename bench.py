@@ -66,6 +66,24 @@ def cpu_baseline(host_view, reps=3):
     }, (a, c)
 
 
+def pmc_traffic(kernel, nbytes):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*_pmc_summary.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH_SIZE x2 correction applied).
+    Counters cannot be read live from inside the timed run; null when no summary matches this workload."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_summary.json"):
+            try:
+                doc = json.load(open(os.path.join(pdir, name)))
+            except ValueError:
+                continue
+            k = doc.get("kernels", {}).get(kernel)
+            if k and doc.get("bytes_per_launch_algorithmic") == nbytes and "hbm_bytes_per_launch_corrected" in k:
+                best = {"bytes": k["hbm_bytes_per_launch_corrected"], "source": "profiles/" + name}
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +215,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": (pmc_traffic("zr::stream_kernel<true, true, false>", n) or {}).get("bytes"),
+                "traffic_source": (pmc_traffic("zr::stream_kernel<true, true, false>", n) or {}).get("source"),
                 "algorithmic_bytes_per_launch": n,
                 "avg_kernel_ms": round(k_avg_ms, 5),
                 "launches_timed": len(kernel_ms),
