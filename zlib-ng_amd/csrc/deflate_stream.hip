@@ -20,6 +20,7 @@
 // hash, 15-bit table), which the reference's own test strategy never requires.
 #include "context.h"
 #include "deflate_dev.h"
+#include "deflate_lz.h"
 
 #include <vector>
 
@@ -172,6 +173,39 @@ void lz_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
                 s = len >= kWantMinMatch ? (0x80000000u | ((len - 3u) << 16) | (dist - 1u)) : 0x40000000u;
             sel[p] = s;
         }
+    }
+}
+
+// Second-generation K1 (deflate_lz.h): exchange-based wavefront insert, ballot-hopping parse,
+// next batch's input prefetched while the current one is parsed.
+__global__ __launch_bounds__(256)
+void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
+    __shared__ uint32_t head[1 << kLzHashBits];
+    __shared__ uint32_t sh_next;
+
+    const StreamJobDev job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t n = job.in_len;
+    uint32_t *sel = sel_base + job.sel_off;
+    const int t = threadIdx.x;
+
+    for (int i = t; i < (1 << kLzHashBits); i += 256) head[i] = 0;
+    if (t == 0) sh_next = 0;
+    __syncthreads();
+
+    uint32_t val = (uint32_t)t + kLzMinMatch <= n ? load_u32(in + t) : 0u;
+    for (uint32_t P = 0; P < n; P += 256) {
+        const uint32_t pn = P + 256u + (uint32_t)t;
+        const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
+        const LzPick r = lz_batch(in, n, P, val, head, &sh_next, t);
+        const uint32_t p = P + (uint32_t)t;
+        if (p < n) {
+            uint32_t s = 0;
+            if (r.visited)
+                s = r.len >= kLzMinMatch ? (0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u)) : 0x40000000u;
+            sel[p] = s;
+        }
+        val = val_next;
     }
 }
 
@@ -405,7 +439,7 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     ZR_HIP(hipMemcpyAsync(g_ds.d_jobs, g_ds.h_jobs.data(), njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_quick_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
+    hipLaunchKernelGGL(lz_quick_kernel2, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel,
