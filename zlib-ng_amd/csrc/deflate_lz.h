@@ -56,7 +56,7 @@ struct LzPick {
 // One batch.  `head` = LDS table (1 << kLzHashBits entries), `sh_next` = LDS word holding the next
 // position the parse will visit.  `val` = the 4 bytes at this lane's position (0 if fewer remain).
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
-                                           uint32_t *head, uint32_t *sh_next, int t) {
+                                           uint32_t *head, uint32_t *sh_next, int t, uint32_t ablate = 0) {
     const int lane = t & 63, wave = t >> 6;
     const uint32_t p = P + (uint32_t)t;
     const bool can = p + kLzMinMatch <= n;              // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
@@ -64,9 +64,14 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
 
     // 1. insert, waves in position order
     uint32_t old = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w && can) old = atomicExch(&head[h], p + 1u);
+    if (ablate & 8u) {                       // timing experiment only: unordered insert
+        if (can) old = atomicExch(&head[h], p + 1u);
         __syncthreads();
+    } else {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && can) old = atomicExch(&head[h], p + 1u);
+            __syncthreads();
+        }
     }
 
     // 2. probe
@@ -76,7 +81,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
             const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
             len = 4;
-            while (len < kLzProbe) {
+            while (len < kLzProbe && !(ablate & 1u)) {
                 if (len + 4 <= maxlen) {
                     const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
                     if (x) {
@@ -95,7 +100,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
 
     // 3. parse
     unsigned long long visited = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 4 && !(ablate & 4u); ++w) {
         if (wave == w) {
             const uint32_t w0 = P + 64u * (uint32_t)w;
             const unsigned long long M = __ballot(len >= kLzMinMatch);
@@ -114,7 +119,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                 uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
                 const uint32_t pabs = w0 + m;
                 const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-                if (L >= kLzProbe && L < maxlen) {
+                if (L >= kLzProbe && L < maxlen && !(ablate & 2u)) {
                     const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
                     uint32_t rem = maxlen - L;
                     if (rem > 256u) rem = 256u;

@@ -22,6 +22,7 @@
 #include "deflate_dev.h"
 #include "deflate_lz.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace zr {
@@ -179,7 +180,7 @@ void lz_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
 // Second-generation K1 (deflate_lz.h): exchange-based wavefront insert, ballot-hopping parse,
 // next batch's input prefetched while the current one is parsed.
 __global__ __launch_bounds__(256)
-void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
+void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t ablate) {
     __shared__ uint32_t head[1 << kLzHashBits];
     __shared__ uint32_t sh_next;
 
@@ -197,7 +198,7 @@ void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restric
     for (uint32_t P = 0; P < n; P += 256) {
         const uint32_t pn = P + 256u + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
-        const LzPick r = lz_batch(in, n, P, val, head, &sh_next, t);
+        const LzPick r = lz_batch(in, n, P, val, head, &sh_next, t, ablate);
         const uint32_t p = P + (uint32_t)t;
         if (p < n) {
             uint32_t s = 0;
@@ -439,7 +440,8 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     ZR_HIP(hipMemcpyAsync(g_ds.d_jobs, g_ds.h_jobs.data(), njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_quick_kernel2, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
+    static const uint32_t ablate = getenv("ZNG_LZ_ABLATE") ? (uint32_t)atoi(getenv("ZNG_LZ_ABLATE")) : 0u;   // timing experiments
+    hipLaunchKernelGGL(lz_quick_kernel2, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel, ablate);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel,
