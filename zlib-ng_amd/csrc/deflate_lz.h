@@ -7,10 +7,17 @@
 //      lane gets back is exactly what quick_insert_string (insert_string_tpl.h:58-75) would have returned
 //      had the 64 positions been inserted one after the other; the four waves of a batch take turns.
 //      (Correctness never depends on that order: every candidate is verified byte by byte.)
-//   2. per-lane probe: first kProbe bytes against the candidate (the zng_memcmp_2 + compare256 of
+//   2. per-lane probe: first kLzProbe bytes against the candidate (the zng_memcmp_2 + compare256 of
 //      deflate_quick.c:96-97, bounded).
-//   3. greedy parse in position order.  Each wave builds ballot(len >= 4) and hops from match to match
-//      (literal runs are skipped with one ctz), long matches are extended with the wavefront-wide compare256.
+//   3. parse.  A greedy parse is a serial chain through the whole stream; here every 64-position REGION
+//      (one wave) parses speculatively from its own first byte, all regions at once: ballot(len >= 4),
+//      hop from match to match with ctz, extend long matches with the wavefront-wide compare256.
+//      Afterwards the regions are stitched: a match that runs past its region covers the head of the next
+//      one(s); tokens that start inside covered bytes are dropped, and the tail of a dropped token that
+//      sticks out of the cover is emitted as literals.  The stitch is a 4-step max-recurrence on
+//      {last match start, region exit}, so the only serial work per batch is O(1).
+//      Every byte is produced exactly once -> the token stream is a valid LZ77 parse; compared with the
+//      strictly serial greedy parse it differs only around region-crossing matches.
 // The head table holds absolute positions + 1 (u32, 0 = empty), so there is no window slide; a stale entry
 // simply fails the distance check (dist <= MAX_DIST, deflate.h:410-415).
 #pragma once
@@ -22,6 +29,14 @@ constexpr int      kLzHashBits = 14;                          // 16384 x u32 = 6
 constexpr uint32_t kLzMaxDist = 32768u - kMinLookahead;       // MAX_DIST(s)
 constexpr uint32_t kLzProbe = 32;                             // bytes compared per lane before the parse
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
+constexpr uint32_t kLzNone = 0xffffffffu;
+
+struct LzShared {                    // LDS state of one stream
+    uint32_t head[1 << kLzHashBits];
+    uint32_t last_start[4];          // per region: start of its last token if that token is a match, else kLzNone
+    uint32_t exit_pos[4];            // per region: first position after its last token
+    uint32_t cover;                  // bytes below this position are already produced (carried across batches)
+};
 
 __device__ __forceinline__ uint32_t lz_hash(uint32_t val) { return (val * 2654435761u) >> (32 - kLzHashBits); }
 
@@ -46,32 +61,25 @@ __device__ __forceinline__ unsigned long long lz_bits_below(uint32_t b) {      /
     return b >= 64 ? ~0ull : ((1ull << b) - 1ull);
 }
 
-// Result of one batch for this lane's position.
 struct LzPick {
-    bool     visited;     // the parse stops at this position (emits a literal or starts a match here)
-    uint32_t len;         // >= kLzMinMatch: match length, else literal
-    uint32_t dist;
+    uint32_t kind;        // 0 = nothing to emit here, 1 = literal, 2 = match
+    uint32_t len, dist;
 };
 
-// One batch.  `head` = LDS table (1 << kLzHashBits entries), `sh_next` = LDS word holding the next
-// position the parse will visit.  `val` = the 4 bytes at this lane's position (0 if fewer remain).
+// One batch.  `val` = the 4 bytes at this lane's position (0 if fewer remain).
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
-                                           uint32_t *head, uint32_t *sh_next, int t, uint32_t ablate = 0) {
-    const int lane = t & 63, wave = t >> 6;
+                                           LzShared *sh, int t) {
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
     const bool can = p + kLzMinMatch <= n;              // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
     const uint32_t h = lz_hash(val);
 
     // 1. insert, waves in position order
     uint32_t old = 0;
-    if (ablate & 8u) {                       // timing experiment only: unordered insert
-        if (can) old = atomicExch(&head[h], p + 1u);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && can) old = atomicExch(&sh->head[h], p + 1u);
         __syncthreads();
-    } else {
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w && can) old = atomicExch(&head[h], p + 1u);
-            __syncthreads();
-        }
     }
 
     // 2. probe
@@ -81,7 +89,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
             const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
             len = 4;
-            while (len < kLzProbe && !(ablate & 1u)) {
+            while (len < kLzProbe) {
                 if (len + 4 <= maxlen) {
                     const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
                     if (x) {
@@ -98,44 +106,70 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         }
     }
 
-    // 3. parse
-    unsigned long long visited = 0;
-    for (int w = 0; w < 4 && !(ablate & 4u); ++w) {
-        if (wave == w) {
-            const uint32_t w0 = P + 64u * (uint32_t)w;
-            const unsigned long long M = __ballot(len >= kLzMinMatch);
-            const uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)*sh_next);
-            uint32_t pos = nxt > w0 ? nxt - w0 : 0u;
-            const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);   // positions of this wave that exist
-            while (pos < lim) {
-                const unsigned long long rest = M >> pos;
-                if (rest == 0) {                                       // literals to the end of the wave
-                    visited |= lz_bits_below(lim) & ~lz_bits_below(pos);
-                    pos = lim;
-                    break;
-                }
-                const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
-                visited |= lz_bits_below(m + 1) & ~lz_bits_below(pos);  // literals [pos, m) and the match start m
-                uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
-                const uint32_t pabs = w0 + m;
-                const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-                if (L >= kLzProbe && L < maxlen && !(ablate & 2u)) {
-                    const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
-                    uint32_t rem = maxlen - L;
-                    if (rem > 256u) rem = 256u;
-                    L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
-                    if ((uint32_t)lane == m) len = L;
-                }
-                pos = m + L;
-            }
-            if (lane == 0) *sh_next = (w0 + pos) > nxt ? (w0 + pos) : nxt;
+    // 3a. speculative parse of this wave's region [w0, w0 + lim)
+    const uint32_t w0 = P + 64u * (uint32_t)wave;
+    const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
+    const unsigned long long M = __ballot(len >= kLzMinMatch);
+    unsigned long long starts = 0;                       // token starts (literals and matches)
+    uint32_t pos = 0, last_start = kLzNone;
+    while (pos < lim) {
+        const unsigned long long rest = M >> pos;
+        if (rest == 0) {                                 // literals to the end of the region
+            starts |= lz_bits_below(lim) & ~lz_bits_below(pos);
+            pos = lim;
+            last_start = kLzNone;
+            break;
         }
-        __syncthreads();
+        const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
+        starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
+        uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
+        const uint32_t pabs = w0 + m;
+        const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
+        if (L >= kLzProbe && L < maxlen) {
+            const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
+            uint32_t rem = maxlen - L;
+            if (rem > 256u) rem = 256u;
+            L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
+            if ((uint32_t)lane == m) len = L;
+        }
+        last_start = pabs;
+        pos = m + L;
     }
+    if (lane == 0) {
+        sh->last_start[wave] = last_start;
+        sh->exit_pos[wave] = w0 + pos;
+    }
+    __syncthreads();
+
+    // 3b. stitch: cover = first position not yet produced when this region starts
+    uint32_t cover = sh->cover;
+    uint32_t carry = cover;
+    for (int v = 0; v < 4; ++v) {
+        if (v == wave) cover = carry;
+        const uint32_t ls = sh->last_start[v], ex = sh->exit_pos[v];
+        const uint32_t region_end = P + 64u * (uint32_t)(v + 1);
+        const uint32_t lim_end = region_end < n ? region_end : n;
+        const bool kept = ls == kLzNone || ls >= carry;            // the region's last token survives the cover
+        const uint32_t out = kept ? ex : lim_end;
+        carry = carry > out ? carry : out;
+    }
+    __syncthreads();                                     // everyone has read sh->cover / last_start / exit_pos
+    if (t == 0) sh->cover = carry;
+
     LzPick r;
-    r.visited = (visited >> lane) & 1ull;
+    r.kind = 0;
     r.len = len;
     r.dist = dist;
+    if (p < n && p >= cover) {
+        if ((starts >> lane) & 1ull) {
+            r.kind = len >= kLzMinMatch ? 2u : 1u;
+        } else {
+            // inside a speculative match that starts at q: orphaned if that match was dropped
+            const unsigned long long below = starts & lz_bits_below((uint32_t)lane);
+            const uint32_t q = w0 + (uint32_t)(63 - __clzll((long long)below));
+            if (q < cover) r.kind = 1u;
+        }
+    }
     return r;
 }
 

@@ -4,12 +4,10 @@
 // (insert_string.c:11-13), a single chain-head probe, compare256, static Huffman trees
 // (zng_tr_emit_lit / zng_tr_emit_dist, trees_emit.h:102-164; RFC 1951 3.2.6) -- re-laid-out for wave64:
 //
-//   K1 lz_quick_kernel   one 256-lane workgroup per stream.  256 consecutive positions per step:
-//        wavefront-wide insert_string (all 256 hashes at once; a position sees earlier positions of
-//        the same step exactly as the sequential loop of insert_string_tpl.h:85-104 would), the head
-//        table (2^15 x u16) lives in LDS and is slid with slide_hash's saturating subtract
-//        (slide_hash_c.c:15-52) every 32 KiB, per-lane probe compare, then a greedy parse in
-//        lane order (readlane), long matches extended with the wavefront-wide compare256.
+//   K1 lz_parse_kernel   one 256-lane workgroup per stream, 256 consecutive positions per step
+//        (deflate_lz.h): wavefront-wide insert_string through one LDS exchange per lane, head table
+//        (2^14 x u32 absolute positions) in LDS, per-lane probe compare, every 64-position region parsed
+//        speculatively in parallel and stitched, long matches extended with the wavefront-wide compare256.
 //        Output: one 32-bit selector per input position (skip / literal / match{len,dist}).
 //   K2 emit_static_kernel one workgroup per stream: static-Huffman code per selector, bit offsets by
 //        a block scan, bits assembled in an LDS tile with ds_or and streamed out with plain stores;
@@ -17,7 +15,7 @@
 //
 // The output is ONE final static block per stream (what deflate_quick emits for a Z_FINISH call),
 // valid RFC 1951; it is not bit-identical to the reference's (every position is inserted into the
-// hash, 15-bit table), which the reference's own test strategy never requires.
+// hash, 14-bit table, region-parallel parse), which the reference's own test strategy never requires.
 #include "context.h"
 #include "deflate_dev.h"
 #include "deflate_lz.h"
@@ -27,11 +25,6 @@
 
 namespace zr {
 
-constexpr int      kQHashBits = 15;
-constexpr uint32_t kQMaxDist = 32768u - kMinLookahead;     // MAX_DIST(s), deflate.h:410-415
-constexpr uint32_t kProbe = 32;                            // bytes compared per lane before the parse
-constexpr uint32_t kWantMinMatch = 4;                      // WANT_MIN_MATCH, deflate.h
-
 struct StreamJobDev {
     const uint8_t *in;
     uint8_t       *out;
@@ -40,149 +33,12 @@ struct StreamJobDev {
     uint64_t       sel_off;      // first selector of this stream in the workspace
 };
 
-__device__ __forceinline__ uint32_t hash15(uint32_t val) { return (val * 2654435761u) >> (32 - kQHashBits); }
-
-// bounded wave-wide compare: number of equal leading bytes of a[0..rem) and b[0..rem), rem <= 256
-__device__ __forceinline__ uint32_t compare_wave_bounded(const uint8_t *a, const uint8_t *b, uint32_t rem, int lane) {
-    const uint32_t off = 4u * (uint32_t)lane;
-    uint32_t x = 0;
-    if (off + 4 <= rem) {
-        x = load_u32(a + off) ^ load_u32(b + off);
-    } else if (off < rem) {
-        for (uint32_t j = 0; off + j < rem; ++j) x |= (uint32_t)(a[off + j] ^ b[off + j]) << (8 * j);
-    }
-    const unsigned long long diff = __ballot(x != 0);
-    if (diff == 0) return rem;
-    const int first = __ffsll((long long)diff) - 1;
-    const uint32_t d = (uint32_t)__shfl((int)x, first, 64);
-    const uint32_t n = (uint32_t)first * 4u + ((uint32_t)(__ffs((int)d) - 1) >> 3);
-    return n < rem ? n : rem;
-}
-
+// K1: LZ77 front end (deflate_lz.h) -- one selector per input position:
+//   0 = produced by an earlier match, 0x40000000 = literal, 0x80000000 | (len-3) << 16 | (dist-1) = match.
+// The next batch's input is prefetched while the current one is parsed.
 __global__ __launch_bounds__(256)
-void lz_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
-    __shared__ uint16_t head[1 << kQHashBits];
-    __shared__ uint32_t sh_next;                     // next position the parse will visit
-
-    const StreamJobDev job = jobs[blockIdx.x];
-    const uint8_t *in = job.in;
-    const uint32_t n = job.in_len;
-    uint32_t *sel = sel_base + job.sel_off;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-
-    for (int i = t; i < (1 << kQHashBits) / 2; i += 256) reinterpret_cast<uint32_t *>(head)[i] = 0;
-    if (t == 0) sh_next = 0;
-    __syncthreads();
-
-    uint32_t wb = 0;                                 // window base: head entries are (position - wb), 0 = empty
-    for (uint32_t P = 0; P < n; P += 256) {
-        if (P + 256u - wb > 65535u) {
-            // slide_hash: entries move down by one window (32 KiB), saturating at 0
-            for (int i = t; i < (1 << kQHashBits) / 2; i += 256) {
-                uint32_t two = reinterpret_cast<uint32_t *>(head)[i];
-                uint32_t lo = two & 0xffffu, hi = two >> 16;
-                lo = lo >= 32768u ? lo - 32768u : 0u;
-                hi = hi >= 32768u ? hi - 32768u : 0u;
-                reinterpret_cast<uint32_t *>(head)[i] = lo | (hi << 16);
-            }
-            wb += 32768u;
-            __syncthreads();
-        }
-        const uint32_t p = P + (uint32_t)t;
-        const bool can = p + kWantMinMatch <= n;       // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
-        const uint32_t val = can ? load_u32(in + p) : 0u;
-        const uint32_t h = can ? hash15(val) : 0xffffffffu;
-
-        // wavefront-wide insert_string, part 1: order among the 64 positions of this wave
-        int before = -1;
-        bool later = false;
-        for (int j = 0; j < 64; ++j) {
-            const uint32_t hj = (uint32_t)__shfl((int)h, j, 64);
-            const bool same = can && hj == h;
-            if (same && j < lane) before = j;
-            if (same && j > lane) later = true;
-        }
-        // part 2: the four waves touch the table in position order
-        uint32_t cand0 = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w && can) {
-                cand0 = head[h];
-                if (!later) head[h] = (uint16_t)(p - wb);
-            }
-            __syncthreads();
-        }
-        uint32_t c = 0xffffffffu;
-        if (can) {
-            if (before >= 0) c = P + (uint32_t)(wave * 64 + before);
-            else if (cand0) c = wb + cand0;
-        }
-
-        // per-lane probe compare (first kProbe bytes)
-        uint32_t len = 0, dist = 0;
-        if (c != 0xffffffffu && c < p && p - c <= kQMaxDist && load_u32(in + c) == val) {
-            const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
-            len = 4;
-            while (len < kProbe) {
-                if (len + 4 <= maxlen) {
-                    const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
-                    if (x) {
-                        len += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                        break;
-                    }
-                    len += 4;
-                } else {
-                    while (len < maxlen && in[p + len] == in[c + len]) ++len;
-                    break;
-                }
-            }
-            dist = p - c;
-        }
-
-        // greedy parse in position order; a wave continues where the previous one stopped
-        unsigned long long visited = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-                const uint32_t w0 = P + 64u * (uint32_t)w;
-                uint32_t nxt = sh_next;
-                uint32_t pos = nxt > w0 ? nxt - w0 : 0u;
-                while (pos < 64u && w0 + pos < n) {
-                    uint32_t L = (uint32_t)__shfl((int)len, (int)pos, 64);
-                    if (L >= kWantMinMatch) {
-                        const uint32_t pabs = w0 + pos;
-                        const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-                        if (L >= kProbe && L < maxlen) {
-                            const uint32_t D = (uint32_t)__shfl((int)dist, (int)pos, 64);
-                            uint32_t rem = maxlen - L;
-                            if (rem > 256u) rem = 256u;
-                            L += compare_wave_bounded(in + pabs + L, in + pabs - D + L, rem, lane);
-                            if ((uint32_t)lane == pos) len = L;
-                        }
-                        visited |= 1ull << pos;
-                        pos += L;
-                    } else {
-                        visited |= 1ull << pos;
-                        pos += 1;
-                    }
-                }
-                if (lane == 0) sh_next = w0 + pos > nxt ? w0 + pos : nxt;
-            }
-            __syncthreads();
-        }
-        if (p < n) {
-            uint32_t s = 0;
-            if ((visited >> lane) & 1ull)
-                s = len >= kWantMinMatch ? (0x80000000u | ((len - 3u) << 16) | (dist - 1u)) : 0x40000000u;
-            sel[p] = s;
-        }
-    }
-}
-
-// Second-generation K1 (deflate_lz.h): exchange-based wavefront insert, ballot-hopping parse,
-// next batch's input prefetched while the current one is parsed.
-__global__ __launch_bounds__(256)
-void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t ablate) {
-    __shared__ uint32_t head[1 << kLzHashBits];
-    __shared__ uint32_t sh_next;
+void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
+    __shared__ LzShared sh;
 
     const StreamJobDev job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
@@ -190,20 +46,20 @@ void lz_quick_kernel2(const StreamJobDev *__restrict__ jobs, uint32_t *__restric
     uint32_t *sel = sel_base + job.sel_off;
     const int t = threadIdx.x;
 
-    for (int i = t; i < (1 << kLzHashBits); i += 256) head[i] = 0;
-    if (t == 0) sh_next = 0;
+    for (int i = t; i < (1 << kLzHashBits); i += 256) sh.head[i] = 0;
+    if (t == 0) sh.cover = 0;
     __syncthreads();
 
     uint32_t val = (uint32_t)t + kLzMinMatch <= n ? load_u32(in + t) : 0u;
     for (uint32_t P = 0; P < n; P += 256) {
         const uint32_t pn = P + 256u + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
-        const LzPick r = lz_batch(in, n, P, val, head, &sh_next, t, ablate);
+        const LzPick r = lz_batch(in, n, P, val, &sh, t);
         const uint32_t p = P + (uint32_t)t;
         if (p < n) {
             uint32_t s = 0;
-            if (r.visited)
-                s = r.len >= kLzMinMatch ? (0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u)) : 0x40000000u;
+            if (r.kind == 2u) s = 0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u);
+            else if (r.kind == 1u) s = 0x40000000u;
             sel[p] = s;
         }
         val = val_next;
@@ -440,8 +296,7 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     ZR_HIP(hipMemcpyAsync(g_ds.d_jobs, g_ds.h_jobs.data(), njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     trace_mark(st, true);
-    static const uint32_t ablate = getenv("ZNG_LZ_ABLATE") ? (uint32_t)atoi(getenv("ZNG_LZ_ABLATE")) : 0u;   // timing experiments
-    hipLaunchKernelGGL(lz_quick_kernel2, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel, ablate);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel,
