@@ -178,6 +178,19 @@ typedef struct zng_rocm_stream_job {
 size_t zng_rocm_deflate_quick_bound(size_t source_len);
 int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, uint32_t *d_results, void *stream);
 
+/* ---- whole-stream deflate on device, ONE large stream (chain-walking levels) -----------------
+ * The caller this replaces is deflate_medium (deflate_medium.c:145-277) + zng_tr_flush_block's
+ * dynamic-tree block (trees.c:625-741) behind DEFLATE_HOOK.  The plaintext is device resident and
+ * complete, so it is compressed as parallel 512 KiB segments (hash primed with the preceding 32 KiB,
+ * so matches cross segment borders) into one continuous raw RFC 1951 stream: one dynamic-Huffman
+ * block per segment, each followed by an empty stored block (byte alignment, as Z_SYNC_FLUSH), and a
+ * final empty static block.  `level` 2..9 selects max_chain_length as deflate.c:142-168 does (capped
+ * at 256).  d_out needs zng_rocm_deflate_bound(in_len) bytes.  Synchronises `stream` (the segment
+ * lengths are prefix-summed on the host).  Returns 0, a ZNG_ROCM_E* code, or -5 (Z_BUF_ERROR). */
+size_t zng_rocm_deflate_bound(size_t source_len);
+int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
+                            size_t *out_len, void *stream);
+
 /* ---- inflate: host bitstream decode -> token stream -> device copy resolution -------------
  * The split of slot `inflate_fast` (inffast_tpl.h:53-318): the sequential Huffman decode loop
  * (:151-226) runs on the host and emits TOKENS instead of stores; the literal stores and match

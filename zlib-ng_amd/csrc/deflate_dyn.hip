@@ -1,0 +1,573 @@
+// deflate_dyn.hip -- level-6 class deflate of ONE large stream on device (BASELINE.json configs[3]).
+//
+// The caller this replaces is deflate_medium (deflate_medium.c:145-277: hash insert, longest_match chain walk,
+// look-ahead for a better match) followed by zng_tr_flush_block's dynamic-tree block (trees.c:625-741), behind
+// DEFLATE_HOOK (deflate.c:1039).  A single zlib stream is strictly serial on a CPU; here the plaintext is
+// already complete in HBM, so it is cut into SEGMENTS that run in parallel:
+//
+//   K1 lz_chain_kernel   one workgroup per segment.  The hash table is primed with the 32 KiB that precede the
+//        segment (what deflateSetDictionary / the sliding window would have left there), then the segment is
+//        parsed with the chain-walking front end of deflate_lz.h (head + prev-delta tables in LDS, 128 KiB).
+//        Matches may reach back into the previous segment: the output is ONE continuous deflate stream.
+//   K2 emit_dynamic_kernel one workgroup per segment = one dynamic-Huffman block: symbol histogram (LDS atomics),
+//        Huffman code lengths (rank sort + two-queue merge, depth limit by frequency halving), canonical codes,
+//        the RLE-coded length header (trees.c send_all_trees equivalent), then the body bits assembled in an
+//        LDS tile exactly like the static emitter.  Each segment ends with an empty stored block so that it is
+//        byte aligned (what Z_SYNC_FLUSH emits, deflate.c:1064-1076); the last one appends the final empty
+//        static block.  K3 packs the segments back to back.
+//
+// Not bit-identical to the reference's stream (different parse, one block per segment, no stored/static
+// block choice yet); validity is defined by round trip, as in the reference's own tests.
+#include "context.h"
+#include "deflate_dev.h"
+#include "deflate_lz.h"
+
+#include <vector>
+
+namespace zr {
+
+struct SegJob {
+    const uint8_t *in;        // stream base (position 0)
+    uint8_t       *out;       // this segment's output slot (4-byte aligned)
+    uint32_t       seg_start, seg_end;
+    uint32_t       out_cap;
+    uint32_t       is_last;
+    uint64_t       sel_off;   // selector index of stream position 0
+};
+
+constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block
+constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
+
+__global__ __launch_bounds__(256)
+void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain) {
+    __shared__ LzShared<true> sh;
+
+    const SegJob job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t n = job.seg_end;                 // matches never run past the segment
+    uint32_t *sel = sel_base + job.sel_off;
+    const int t = threadIdx.x;
+
+    for (int i = t; i < (1 << kLzHashBits); i += 256) sh.head[i] = 0;
+    for (int i = t; i < 32768 / 2; i += 256) reinterpret_cast<uint32_t *>(sh.prev)[i] = 0;
+    if (t == 0) sh.cover = job.seg_start;
+    __syncthreads();
+
+    uint32_t P0 = job.seg_start > kPrime ? job.seg_start - kPrime : 0u;
+    P0 &= ~255u;
+    const uint32_t first = job.seg_start & ~255u;   // batch holding the first byte of the segment
+    uint32_t val = P0 + (uint32_t)t + kLzMinMatch <= n ? load_u32(in + P0 + t) : 0u;
+    for (uint32_t P = P0; P < n; P += 256) {
+        const uint32_t pn = P + 256u + (uint32_t)t;
+        const uint32_t val_next = (pn + kLzMinMatch <= n) ? load_u32(in + pn) : 0u;
+        const bool prime = P < first;
+        const LzPick r = lz_batch<true>(in, n, P, val, &sh, t, max_chain, prime);
+        const uint32_t p = P + (uint32_t)t;
+        if (!prime && p >= job.seg_start && p < n) {
+            uint32_t s = 0;
+            if (r.kind == 2u) s = 0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u);
+            else if (r.kind == 1u) s = 0x40000000u;
+            sel[p] = s;
+        }
+        val = val_next;
+    }
+}
+
+// ---- dynamic Huffman ---------------------------------------------------------------------------------------
+struct DynTables {                 // LDS
+    uint32_t lfreq[288];
+    uint32_t dfreq[32];
+    uint8_t  llen[288];
+    uint8_t  dlen[32];
+    uint16_t lcode[288];           // bit-reversed canonical codes
+    uint16_t dcode[32];
+    // scratch of the tree builder
+    uint32_t w[2 * 288];           // weights: sorted leaves [0, m), internal nodes [288, 288 + m - 1)
+    uint16_t sym[288];             // leaf rank -> symbol
+    uint16_t kid[2][288];          // children of internal node k (index < 288: leaf rank, >= 288: internal)
+    uint8_t  depth[2 * 288];
+    // code-length header
+    uint8_t  clsym[320];
+    uint8_t  clext[320];
+    uint32_t clfreq[19];
+    uint8_t  cllen[19];
+    uint16_t clcode[19];
+    uint32_t ncl, hlit, hdist, hclen;
+};
+
+// Code lengths (<= maxbits) for freq[0..n) into len[0..n).  All 256 lanes call it; serial parts run on lane 0.
+// Equivalent of build_tree + gen_bitlen (trees.c) -- lengths are optimal Huffman lengths unless the depth
+// limit is hit, in which case frequencies are halved until the tree fits (still a complete prefix code).
+__device__ void huff_lengths(DynTables *T, uint32_t *freq, int n, int maxbits, uint8_t *len, int t) {
+    // at least two codes, as zlib forces (trees.c build_tree: "force at least two codes of non zero frequency")
+    __syncthreads();
+    if (t == 0) {
+        int used = 0;
+        for (int i = 0; i < n; ++i) used += freq[i] != 0;
+        for (int i = 0; used < 2 && i < n; ++i)
+            if (freq[i] == 0) {
+                freq[i] = 1;
+                ++used;
+            }
+    }
+    __syncthreads();
+    for (;;) {
+        // rank sort of the used symbols by (freq, symbol)
+        for (int s = t; s < n; s += 256) {
+            const uint32_t f = freq[s];
+            if (f) {
+                int rank = 0;
+                for (int j = 0; j < n; ++j) {
+                    const uint32_t g = freq[j];
+                    rank += (g != 0) && (g < f || (g == f && j < s));
+                }
+                T->w[rank] = f;
+                T->sym[rank] = (uint16_t)s;
+            }
+        }
+        __syncthreads();
+        __shared__ int m_used, too_deep;
+        if (t == 0) {
+            int m = 0;
+            for (int i = 0; i < n; ++i) m += freq[i] != 0;
+            m_used = m;
+            // two-queue merge: leaves ascending in w[0..m), internal nodes appended at w[288..]
+            int li = 0, ii = 0, ni = 0;                       // next leaf, next internal, internal count
+            for (int k = 0; k + 1 < m; ++k) {
+                uint32_t sum = 0;
+                for (int c = 0; c < 2; ++c) {
+                    const bool take_leaf = li < m && (ii >= ni || T->w[li] <= T->w[288 + ii]);
+                    if (take_leaf) { sum += T->w[li]; T->kid[c][ni] = (uint16_t)li; ++li; }
+                    else           { sum += T->w[288 + ii]; T->kid[c][ni] = (uint16_t)(288 + ii); ++ii; }
+                }
+                T->w[288 + ni] = sum;
+                ++ni;
+            }
+            // depths, root = last internal node
+            int deepest = 0;
+            T->depth[288 + ni - 1] = 0;
+            for (int k = ni - 1; k >= 0; --k) {
+                const uint8_t d = (uint8_t)(T->depth[288 + k] + 1);
+                for (int c = 0; c < 2; ++c) T->depth[T->kid[c][k]] = d;
+                if (d > deepest) deepest = d;
+            }
+            too_deep = deepest > maxbits;
+        }
+        __syncthreads();
+        if (!too_deep) break;
+        for (int s = t; s < n; s += 256)
+            if (freq[s]) freq[s] = (freq[s] + 1) >> 1;
+        __syncthreads();
+    }
+    for (int s = t; s < n; s += 256) len[s] = 0;
+    __syncthreads();
+    __shared__ int m_copy;
+    if (t == 0) {
+        int m = 0;
+        for (int i = 0; i < n; ++i) m += freq[i] != 0;
+        m_copy = m;
+    }
+    __syncthreads();
+    for (int r = t; r < m_copy; r += 256) len[T->sym[r]] = T->depth[r];
+    __syncthreads();
+}
+
+// canonical codes (RFC 1951 3.2.2, gen_codes of trees.c), bit-reversed for LSB-first packing
+__device__ void huff_codes(const uint8_t *len, int n, uint16_t *code, int t) {
+    for (int s = t; s < n; s += 256) {
+        const int l = len[s];
+        uint32_t c = 0;
+        if (l) {
+            // first code of length l = sum over shorter lengths, then rank among equal lengths
+            uint32_t cnt[16];
+            for (int i = 0; i < 16; ++i) cnt[i] = 0;
+            uint32_t before = 0;
+            for (int j = 0; j < n; ++j) {
+                const int lj = len[j];
+                cnt[lj]++;
+                before += (lj == l && j < s);
+            }
+            uint32_t first = 0;
+            cnt[0] = 0;
+            for (int b = 1; b <= l; ++b) first = (first + cnt[b - 1]) << 1;
+            c = __brev(first + before) >> (32 - l);
+        }
+        code[s] = (uint16_t)c;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void len_symbol(uint32_t len, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    const uint32_t l = len - 3;
+    eb = 0;
+    ev = 0;
+    if (l < 8) sym = 257 + l;
+    else if (l == 255) sym = 285;
+    else {
+        const uint32_t lg = 31u - (uint32_t)__clz((int)l);
+        eb = lg - 2;
+        sym = 257 + 4 * eb + 4 + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1u);
+    }
+}
+
+__device__ __forceinline__ void dist_symbol(uint32_t dist, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    const uint32_t x = dist - 1;
+    eb = 0;
+    ev = 0;
+    if (x < 4) sym = x;
+    else {
+        const uint32_t lg = 31u - (uint32_t)__clz((int)x);
+        eb = lg - 1;
+        sym = 2 * lg + ((x >> eb) & 1u);
+        ev = x & ((1u << eb) - 1u);
+    }
+}
+
+constexpr int kDynPer = 16;
+constexpr int kDynTile = 256 * kDynPer;
+constexpr int kDynWords = 2 * kDynTile + 16;       // worst case 48 bits per position
+
+__device__ __forceinline__ void lds_put(uint32_t *obuf, uint32_t &cur, uint32_t bits, uint32_t nb) {
+    if (!nb) return;
+    const uint32_t word = cur >> 5, sh = cur & 31u;
+    atomicOr(&obuf[word], bits << sh);
+    if (sh + nb > 32u) atomicOr(&obuf[word + 1], bits >> (32u - sh));
+    cur += nb;
+}
+
+__global__ __launch_bounds__(256)
+void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ sel_base,
+                         uint32_t *__restrict__ seg_len) {
+    __shared__ DynTables T;
+    __shared__ uint32_t obuf[kDynWords];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t sh_cw, sh_cbits, sh_wbase;
+
+    const SegJob job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t lo = job.seg_start, hi = job.seg_end;
+    const uint32_t *sel = sel_base + job.sel_off;
+    uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // 1. histogram
+    for (int i = t; i < 288; i += 256) T.lfreq[i] = 0;
+    if (t < 32) T.dfreq[t] = 0;
+    __syncthreads();
+    for (uint32_t p = lo + (uint32_t)t; p < hi; p += 256) {
+        const uint32_t s = sel[p];
+        if (s & 0x80000000u) {
+            uint32_t sym, eb, ev;
+            len_symbol(((s >> 16) & 0xffu) + 3u, sym, eb, ev);
+            atomicAdd(&T.lfreq[sym], 1u);
+            dist_symbol((s & 0xffffu) + 1u, sym, eb, ev);
+            atomicAdd(&T.dfreq[sym], 1u);
+        } else if (s & 0x40000000u) {
+            atomicAdd(&T.lfreq[in[p]], 1u);
+        }
+    }
+    if (t == 0) atomicAdd(&T.lfreq[256], 1u);           // end-of-block
+    __syncthreads();
+
+    // 2. code lengths and codes
+    huff_lengths(&T, T.lfreq, 286, 15, T.llen, t);
+    huff_lengths(&T, T.dfreq, 30, 15, T.dlen, t);
+    huff_codes(T.llen, 286, T.lcode, t);
+    huff_codes(T.dlen, 30, T.dcode, t);
+
+    // 3. run-length code the lengths (scan_tree / send_tree of trees.c; RFC 1951 3.2.7)
+    if (t == 0) {
+        int hlit = 286, hdist = 30;
+        while (hlit > 257 && T.llen[hlit - 1] == 0) --hlit;
+        while (hdist > 1 && T.dlen[hdist - 1] == 0) --hdist;
+        T.hlit = hlit;
+        T.hdist = hdist;
+        for (int i = 0; i < 19; ++i) T.clfreq[i] = 0;
+        const int total = hlit + hdist;
+        int ncl = 0, i = 0;
+        while (i < total) {
+            const int v = i < hlit ? T.llen[i] : T.dlen[i - hlit];
+            int run = 1;
+            while (i + run < total && (i + run < hlit ? T.llen[i + run] : T.dlen[i + run - hlit]) == v) ++run;
+            i += run;
+            if (v == 0) {
+                while (run >= 11) {
+                    const int r = run > 138 ? 138 : run;
+                    T.clsym[ncl] = 18; T.clext[ncl++] = (uint8_t)(r - 11); T.clfreq[18]++;
+                    run -= r;
+                }
+                if (run >= 3) {
+                    T.clsym[ncl] = 17; T.clext[ncl++] = (uint8_t)(run - 3); T.clfreq[17]++;
+                    run = 0;
+                }
+                while (run-- > 0) { T.clsym[ncl] = 0; T.clext[ncl++] = 0; T.clfreq[0]++; }
+            } else {
+                T.clsym[ncl] = (uint8_t)v; T.clext[ncl++] = 0; T.clfreq[v]++;
+                --run;
+                while (run >= 3) {
+                    const int r = run > 6 ? 6 : run;
+                    T.clsym[ncl] = 16; T.clext[ncl++] = (uint8_t)(r - 3); T.clfreq[16]++;
+                    run -= r;
+                }
+                while (run-- > 0) { T.clsym[ncl] = (uint8_t)v; T.clext[ncl++] = 0; T.clfreq[v]++; }
+            }
+        }
+        T.ncl = ncl;
+    }
+    __syncthreads();
+    huff_lengths(&T, T.clfreq, 19, 7, T.cllen, t);
+    huff_codes(T.cllen, 19, T.clcode, t);
+
+    // 4. header bits, serial (a few hundred bits)
+    for (int i = t; i < kDynWords; i += 256) obuf[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && T.cllen[order[hclen - 1]] == 0) --hclen;
+        uint32_t cur = 0;
+        lds_put(obuf, cur, 0u | (2u << 1), 3);                         // BFINAL = 0, BTYPE = 10 (dynamic)
+        lds_put(obuf, cur, T.hlit - 257, 5);
+        lds_put(obuf, cur, T.hdist - 1, 5);
+        lds_put(obuf, cur, (uint32_t)hclen - 4, 4);
+        for (int i = 0; i < hclen; ++i) lds_put(obuf, cur, T.cllen[order[i]], 3);
+        for (uint32_t i = 0; i < T.ncl; ++i) {
+            const uint32_t s = T.clsym[i];
+            lds_put(obuf, cur, T.clcode[s], T.cllen[s]);
+            if (s == 16) lds_put(obuf, cur, T.clext[i], 2);
+            else if (s == 17) lds_put(obuf, cur, T.clext[i], 3);
+            else if (s == 18) lds_put(obuf, cur, T.clext[i], 7);
+        }
+        // flush whole words of the header, keep the partial one as the carry
+        const uint32_t full = cur >> 5;
+        for (uint32_t i = 0; i < full; ++i) outw[i] = obuf[i];
+        sh_wbase = full;
+        sh_cw = obuf[full];
+        sh_cbits = cur & 31u;
+    }
+    __syncthreads();
+    uint32_t wbase = sh_wbase, cw = sh_cw, cbits = sh_cbits;
+
+    // 5. body
+    for (uint32_t base = lo; base < hi; base += kDynTile) {
+        const uint32_t p0 = base + (uint32_t)t * kDynPer;
+        uint32_t c1[kDynPer], n1[kDynPer], c2[kDynPer], n2[kDynPer];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kDynPer; ++j) {
+            const uint32_t p = p0 + (uint32_t)j;
+            const uint32_t s = p < hi ? sel[p] : 0u;
+            c1[j] = n1[j] = c2[j] = n2[j] = 0;
+            if (s & 0x80000000u) {
+                uint32_t sym, eb, ev;
+                len_symbol(((s >> 16) & 0xffu) + 3u, sym, eb, ev);
+                c1[j] = (uint32_t)T.lcode[sym] | (ev << T.llen[sym]);
+                n1[j] = T.llen[sym] + eb;
+                dist_symbol((s & 0xffffu) + 1u, sym, eb, ev);
+                c2[j] = (uint32_t)T.dcode[sym] | (ev << T.dlen[sym]);
+                n2[j] = T.dlen[sym] + eb;
+            } else if (s & 0x40000000u) {
+                const uint32_t b = in[p];
+                c1[j] = T.lcode[b];
+                n1[j] = T.llen[b];
+            }
+            mine += n1[j] + n2[j];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        for (int i = t; i < kDynWords; i += 256) obuf[i] = 0;
+        __syncthreads();
+        uint32_t wave_off = 0, tile_bits = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wave_off += wave_tot[w];
+            tile_bits += wave_tot[w];
+        }
+        if (t == 0) obuf[0] = cw;
+        __syncthreads();
+        uint32_t cur = cbits + wave_off + incl - mine;
+#pragma unroll
+        for (int j = 0; j < kDynPer; ++j) {
+            lds_put(obuf, cur, c1[j], n1[j]);
+            lds_put(obuf, cur, c2[j], n2[j]);
+        }
+        __syncthreads();
+        const uint32_t total = cbits + tile_bits;
+        const uint32_t full = total >> 5;
+        for (uint32_t i = (uint32_t)t; i < full; i += 256) outw[wbase + i] = obuf[i];
+        const uint32_t next_cw = obuf[full];
+        __syncthreads();
+        wbase += full;
+        cw = next_cw;
+        cbits = total & 31u;
+    }
+
+    // 6. end of block, then an empty stored block to reach a byte boundary (and the final block at the very end)
+    if (t == 0) {
+        uint8_t *outb = job.out;
+        unsigned long long acc = cw;                      // bit accumulator
+        uint32_t nb = cbits;
+        uint32_t bytes = wbase * 4u;
+        auto put = [&](uint32_t bits, uint32_t n) {
+            acc |= (unsigned long long)bits << nb;
+            nb += n;
+            while (nb >= 8) {
+                outb[bytes++] = (uint8_t)acc;
+                acc >>= 8;
+                nb -= 8;
+            }
+        };
+        put(T.lcode[256], T.llen[256]);
+        put(0, 3);                                        // stored block header, BFINAL = 0
+        if (nb) put(0, 8 - nb);                           // pad to a byte
+        put(0x0000, 16);
+        put(0xffff, 16);                                  // LEN = 0, NLEN = ~0
+        if (job.is_last) {
+            put(3, 3);                                    // BFINAL = 1, BTYPE = 01
+            put(0, 7);                                    // its end-of-block code
+            if (nb) put(0, 8 - nb);
+        }
+        seg_len[blockIdx.x] = bytes;
+    }
+}
+
+// K3: pack the segments back to back (byte granular)
+__global__ __launch_bounds__(256)
+void gather_segments_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len,
+                            const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst) {
+    const SegJob job = jobs[blockIdx.y];
+    const uint32_t n = seg_len[blockIdx.y];
+    uint8_t *d = dst + dst_off[blockIdx.y];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = job.out[i];
+}
+
+struct DynScratch {
+    SegJob   *d_jobs = nullptr;
+    size_t    job_cap = 0;
+    uint32_t *d_sel = nullptr;
+    size_t    sel_cap = 0;
+    uint8_t  *d_slots = nullptr;
+    size_t    slot_cap = 0;
+    uint32_t *d_seg_len = nullptr;
+    uint64_t *d_dst_off = nullptr;
+};
+static DynScratch g_dyn;
+
+static inline size_t seg_slot_bytes(uint32_t n) {
+    // <= 9 bits per literal for an almost flat alphabet, + header (< 400 bytes) + trailer; 4-byte aligned
+    return (((size_t)n * 9 + 7) / 8 + 1024 + 3) & ~(size_t)3;
+}
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+size_t zng_rocm_deflate_bound(size_t source_len) {
+    const size_t nseg = source_len ? (source_len + kSegBytes - 1) / kSegBytes : 1;
+    return source_len + source_len / 8 + nseg * 1032 + 16;
+}
+
+int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
+                         size_t *out_len, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!out_len || !d_out || (!d_in && in_len)) return ZNG_ROCM_EINVAL;
+    if (level < 2 || level > 9) {
+        set_error("zng_rocm_deflate_dev implements the chain-walking levels (2..9); level 1 is zng_rocm_deflate_quick_dev");
+        return ZNG_ROCM_EINVAL;
+    }
+    if (in_len >= (1ull << 32) - kSegBytes) {
+        set_error("streams of 4 GiB and more are not supported by the 32-bit position format");
+        return ZNG_ROCM_EINVAL;
+    }
+    if (out_cap < zng_rocm_deflate_bound(in_len)) {
+        set_error("out_cap below zng_rocm_deflate_bound()");
+        return -5;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // max_chain_length per level, deflate.c:142-168
+    static const uint32_t chains[10] = {0, 4, 4, 6, 24, 32, 128, 256, 1024, 4096};
+    uint32_t max_chain = chains[level];
+    if (max_chain > 256) max_chain = 256;
+
+    const size_t nseg = in_len ? (in_len + kSegBytes - 1) / kSegBytes : 1;
+    std::vector<SegJob> jobs(nseg);
+    size_t slot_total = 0;
+    for (size_t i = 0; i < nseg; ++i) {
+        const uint32_t a = (uint32_t)(i * kSegBytes);
+        const uint32_t b = (uint32_t)((i + 1) * kSegBytes < in_len ? (i + 1) * kSegBytes : in_len);
+        jobs[i].in = d_in;
+        jobs[i].seg_start = a;
+        jobs[i].seg_end = b;
+        jobs[i].out_cap = (uint32_t)seg_slot_bytes(b - a);
+        jobs[i].is_last = i + 1 == nseg;
+        jobs[i].sel_off = 0;
+        jobs[i].out = (uint8_t *)slot_total;          // offset for now
+        slot_total += jobs[i].out_cap;
+    }
+    if (nseg > g_dyn.job_cap) {
+        if (g_dyn.d_jobs) (void)hipFree(g_dyn.d_jobs);
+        if (g_dyn.d_seg_len) (void)hipFree(g_dyn.d_seg_len);
+        if (g_dyn.d_dst_off) (void)hipFree(g_dyn.d_dst_off);
+        g_dyn.job_cap = 0;
+        ZR_HIP(hipMalloc(&g_dyn.d_jobs, nseg * sizeof(SegJob)));
+        ZR_HIP(hipMalloc(&g_dyn.d_seg_len, nseg * sizeof(uint32_t)));
+        ZR_HIP(hipMalloc(&g_dyn.d_dst_off, nseg * sizeof(uint64_t)));
+        g_dyn.job_cap = nseg;
+    }
+    if (in_len + 1024 > g_dyn.sel_cap) {
+        if (g_dyn.d_sel) (void)hipFree(g_dyn.d_sel);
+        g_dyn.sel_cap = 0;
+        ZR_HIP(hipMalloc(&g_dyn.d_sel, (in_len + 1024) * sizeof(uint32_t)));
+        g_dyn.sel_cap = in_len + 1024;
+    }
+    if (slot_total > g_dyn.slot_cap) {
+        if (g_dyn.d_slots) (void)hipFree(g_dyn.d_slots);
+        g_dyn.slot_cap = 0;
+        ZR_HIP(hipMalloc(&g_dyn.d_slots, slot_total));
+        g_dyn.slot_cap = slot_total;
+    }
+    for (size_t i = 0; i < nseg; ++i) jobs[i].out = g_dyn.d_slots + (size_t)jobs[i].out;
+    ZR_HIP(hipMemcpyAsync(g_dyn.d_jobs, jobs.data(), nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
+
+    trace_mark(st, true);
+    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain);
+    trace_mark(st, false);
+    ZR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel,
+                       g_dyn.d_seg_len);
+    ZR_HIP(hipGetLastError());
+
+    // segment lengths -> offsets (host; the one synchronisation of this entry point)
+    std::vector<uint32_t> lens(nseg);
+    ZR_HIP(hipMemcpyAsync(lens.data(), g_dyn.d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> offs(nseg);
+    uint64_t total = 0;
+    for (size_t i = 0; i < nseg; ++i) {
+        offs[i] = total;
+        total += lens[i];
+    }
+    if (total > out_cap) {
+        set_error("compressed size %llu exceeds out_cap", (unsigned long long)total);
+        return -5;
+    }
+    ZR_HIP(hipMemcpyAsync(g_dyn.d_dst_off, offs.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs,
+                       g_dyn.d_seg_len, g_dyn.d_dst_off, d_out);
+    ZR_HIP(hipGetLastError());
+    ZR_HIP(hipStreamSynchronize(st));
+    *out_len = (size_t)total;
+    return ZNG_ROCM_OK;
+}
+
+}  // extern "C"

@@ -31,8 +31,13 @@ constexpr uint32_t kLzProbe = 32;                             // bytes compared 
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
 constexpr uint32_t kLzNone = 0xffffffffu;
 
+constexpr uint32_t kLzChainProbe = 64;                        // chain mode: per-lane compare cap (= "nice" length)
+
+template <bool CHAIN>
 struct LzShared {                    // LDS state of one stream
     uint32_t head[1 << kLzHashBits];
+    uint16_t prev[CHAIN ? 32768 : 2];  // CHAIN: distance from a position to the previous one with the same hash (0 = none);
+                                     //        the `prev` links of insert_string_tpl.h:98-102, stored as deltas
     uint32_t last_start[4];          // per region: start of its last token if that token is a match, else kLzNone
     uint32_t exit_pos[4];            // per region: first position after its last token
     uint32_t cover;                  // bytes below this position are already produced (carried across batches)
@@ -67,8 +72,14 @@ struct LzPick {
 };
 
 // One batch.  `val` = the 4 bytes at this lane's position (0 if fewer remain).
+// CHAIN = false: level-1 class, a single chain-head probe (deflate_quick.c:89-97).
+// CHAIN = true : level-6 class: walk up to `max_chain` links keeping the longest match, the loop of
+//                longest_match (match_tpl.h:129-268) with its end-of-best-match quick reject (:167-173), then a
+//                one-step lazy evaluation in the parse (a longer match at the next byte wins, cf. max_lazy 16 of
+//                deflate.c:163).  `insert_only` batches just enter their positions (dictionary priming).
+template <bool CHAIN>
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
-                                           LzShared *sh, int t) {
+                                           LzShared<CHAIN> *sh, int t, uint32_t max_chain = 0, bool insert_only = false) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
@@ -81,28 +92,80 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         if (wave == w && can) old = atomicExch(&sh->head[h], p + 1u);
         __syncthreads();
     }
+    if constexpr (CHAIN) {
+        if (can) {
+            const uint32_t d = old ? p - (old - 1u) : 0u;
+            sh->prev[p & 32767u] = (uint16_t)(d <= 65535u ? d : 0u);
+        }
+        if (insert_only) {
+            LzPick none;
+            none.kind = 0;
+            none.len = none.dist = 0;
+            return none;
+        }
+        __syncthreads();                                 // links of this batch are visible to every walker
+    }
 
     // 2. probe
     uint32_t len = 0, dist = 0;
-    if (old) {
-        const uint32_t c = old - 1u;
-        if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
-            const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
-            len = 4;
-            while (len < kLzProbe) {
-                if (len + 4 <= maxlen) {
-                    const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
-                    if (x) {
-                        len += (uint32_t)(__ffs((int)x) - 1) >> 3;
+    if constexpr (!CHAIN) {
+        if (old) {
+            const uint32_t c = old - 1u;
+            if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
+                const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
+                len = 4;
+                while (len < kLzProbe) {
+                    if (len + 4 <= maxlen) {
+                        const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
+                        if (x) {
+                            len += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                            break;
+                        }
+                        len += 4;
+                    } else {
+                        while (len < maxlen && in[p + len] == in[c + len]) ++len;
                         break;
                     }
-                    len += 4;
-                } else {
-                    while (len < maxlen && in[p + len] == in[c + len]) ++len;
-                    break;
                 }
+                dist = p - c;
             }
-            dist = p - c;
+        }
+    } else {
+        if (old) {
+            const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
+            uint32_t c = old - 1u;
+            uint32_t best = 3;                           // a match must reach WANT_MIN_MATCH to count
+            uint32_t chain = max_chain;
+            while (c < p && p - c <= kLzMaxDist) {
+                // quick reject on the 4 bytes ending at `best` (they must all match to beat it) and on the first 4
+                if (best + 1 <= maxlen && load_u32(in + c + best - 3) == load_u32(in + p + best - 3) &&
+                    load_u32(in + c) == val) {
+                    uint32_t l = 4;
+                    while (l < kLzChainProbe) {
+                        if (l + 4 <= maxlen) {
+                            const uint32_t x = load_u32(in + p + l) ^ load_u32(in + c + l);
+                            if (x) {
+                                l += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                                break;
+                            }
+                            l += 4;
+                        } else {
+                            while (l < maxlen && in[p + l] == in[c + l]) ++l;
+                            break;
+                        }
+                    }
+                    if (l > best) {
+                        best = l;
+                        dist = p - c;
+                        if (l >= kLzChainProbe || l >= maxlen) break;      // nice_match reached
+                    }
+                }
+                if (--chain == 0) break;
+                const uint32_t d = sh->prev[c & 32767u];
+                if (d == 0 || d > c) break;
+                c -= d;
+            }
+            if (best >= kLzMinMatch) len = best;
         }
     }
 
@@ -120,12 +183,21 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
             last_start = kLzNone;
             break;
         }
-        const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
-        starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
+        uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
         uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
+        if constexpr (CHAIN) {
+            // lazy evaluation: a strictly longer match one byte later turns this byte into a literal
+            while (L < 16u && m + 1u < lim) {
+                const uint32_t L2 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)(m + 1u));
+                if (L2 <= L) break;
+                ++m;
+                L = L2;
+            }
+        }
+        starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
         const uint32_t pabs = w0 + m;
         const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-        if (L >= kLzProbe && L < maxlen) {
+        if (L >= (CHAIN ? kLzChainProbe : kLzProbe) && L < maxlen) {
             const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
             uint32_t rem = maxlen - L;
             if (rem > 256u) rem = 256u;

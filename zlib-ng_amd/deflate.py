@@ -63,3 +63,22 @@ class QuickBatch:
         clen = int(res[i, 0])
         o = self.out_off[i]
         return self.dst[o:o + clen].cpu().numpy().tobytes()
+
+
+def deflate_bound(n):
+    return rocm.lib().zng_rocm_deflate_bound(n)
+
+
+def deflate_dev(src, level=6, length=None, offset=0, stream=None):
+    """one large device-resident stream -> (uint8 CUDA tensor with the raw deflate stream, compressed length).
+    level 2..9 (chain-walking levels; level 1 is QuickBatch)."""
+    import torch
+    rocm._need_init()
+    n = src.numel() - offset if length is None else length
+    cap = deflate_bound(n)
+    dst = torch.empty(cap, dtype=torch.uint8, device=src.device)
+    out_len = C.c_size_t(0)
+    rc = rocm.lib().zng_rocm_deflate_dev(level, rocm._dev_ptr(src, offset), n, rocm._dev_ptr(dst), cap,
+                                         C.byref(out_len), rocm._stream_ptr(stream))
+    rocm._check(rc, "zng_rocm_deflate_dev")
+    return dst, out_len.value

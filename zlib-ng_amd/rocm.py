@@ -60,6 +60,9 @@ _PROTOS = {
     "zng_rocm_chunkmemset_safe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]),
     "zng_rocm_chunksize": (C.c_uint32, []),
+    "zng_rocm_deflate_bound": (C.c_size_t, [C.c_size_t]),
+    "zng_rocm_deflate_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.c_void_p]),
     "zng_rocm_deflate_quick_bound": (C.c_size_t, [C.c_size_t]),
     "zng_rocm_deflate_quick_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_inflate_tokens_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
