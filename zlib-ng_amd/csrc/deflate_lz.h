@@ -174,6 +174,8 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
     const unsigned long long M = __ballot(len >= kLzMinMatch);
     unsigned long long starts = 0;                       // token starts (literals and matches)
+    unsigned long long mstarts = 0;                      // the starts that are matches (lazy evaluation can demote a lane
+                                                         // with len >= 4 to a literal)
     uint32_t pos = 0, last_start = kLzNone;
     while (pos < lim) {
         const unsigned long long rest = M >> pos;
@@ -195,6 +197,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
             }
         }
         starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
+        mstarts |= 1ull << m;
         const uint32_t pabs = w0 + m;
         const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
         if (L >= (CHAIN ? kLzChainProbe : kLzProbe) && L < maxlen) {
@@ -234,7 +237,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     r.dist = dist;
     if (p < n && p >= cover) {
         if ((starts >> lane) & 1ull) {
-            r.kind = len >= kLzMinMatch ? 2u : 1u;
+            r.kind = ((mstarts >> lane) & 1ull) ? 2u : 1u;
         } else {
             // inside a speculative match that starts at q: orphaned if that match was dropped
             const unsigned long long below = starts & lz_bits_below((uint32_t)lane);
