@@ -155,6 +155,46 @@ def main():
             "cpu_python_zlib_deflate6_in_MBps_1thread": round(n / 1e6 / t_comp, 1)}
         del d_tok, d_lit, d_seg, d_sym, d_out, dst
 
+    # ---- cfg4: deflate level 6 of one 256 MiB stream -----------------------------------------------------
+    if want("cfg4"):
+        n = (32 if args.quick else 256) << 20
+        plain = synth.silesia_like(n, seed=0x5EED0003)
+        src = torch.from_numpy(plain).cuda()
+        dst, clen = dfl.deflate_dev(src, level=6)                 # warm-up (allocates the workspaces)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dst, clen = dfl.deflate_dev(src, level=6)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        zr.trace_begin(4)
+        dst, clen = dfl.deflate_dev(src, level=6)
+        k1 = zr.trace_end(4)
+        comp = dst[:clen].cpu().numpy().tobytes()
+        t0 = time.perf_counter()
+        back = zlib.decompressobj(-15).decompress(comp)           # independent inflater (classic zlib)
+        t_inf = time.perf_counter() - t0
+        ok = back == plain.tobytes()
+        del back
+        dec = inf.decode_tokens(comp)                             # and the product's own inflate path
+        ok2 = dec.status == 1 and torch.equal(inf.resolve_dev(dec), src)
+        sample = plain[:32 << 20].tobytes()
+        t0 = time.perf_counter()
+        z6 = len(zlib.compress(sample, 6))
+        t_z6 = time.perf_counter() - t0
+        step = statistics.median(times)
+        report["cfg4"] = {
+            "workload": "deflate level-6 class of one %d MiB stream (Silesia-like mix), device resident, raw" % (n >> 20),
+            "round_trip_ok_python_zlib": bool(ok), "round_trip_ok_product_inflate": bool(ok2),
+            "ratio": round(n / clen, 3), "compressed_MiB": round(clen / 2**20, 2),
+            "step_s_incl_host_sync": round(step, 4), "input_GBps": round(n / 1e9 / step, 2),
+            "algorithmic_GBps_U_plus_C": round((n + clen) / 1e9 / step, 2),
+            "lz_chain_kernel_ms": round(k1[0], 2) if k1 else None,
+            "cpu_python_zlib_level6_in_MBps_1thread": round(len(sample) / 1e6 / t_z6, 1),
+            "cpu_python_zlib_level6_ratio_on_first_32MiB": round(len(sample) / z6, 3)}
+        del src, dst
+
     # ---- cfg5: 4096 independent 1 MiB streams, level-1 class, one GPU's view ----------------------------
     if want("cfg5"):
         nstreams = 256 if args.quick else 4096
