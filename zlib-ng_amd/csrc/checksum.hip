@@ -30,6 +30,14 @@
 
 namespace zr {
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// streaming (read-once) 16-byte load: non-temporal hint, the data is never re-read
+__device__ __forceinline__ uint4 ld_stream(const uint8_t *p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // first `k` bytes (k in 0..15) of a piece -> 0
 __device__ __forceinline__ uint4 mask_low_bytes(uint4 v, int k) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -151,25 +159,53 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
         ++u;
     }
 
+    // Main loop, software pipelined with two register buffers (ping-pong, no copies): while group k is
+    // consumed the UNROLL rows of group k+1 are already in flight, so every lane keeps UNROLL..2*UNROLL
+    // dwordx4 loads outstanding (16 waves x 4..8 KiB per CU) and each wait is a counted vmcnt(UNROLL).
     constexpr int UNROLL = 4;
     constexpr int BATCH_MAX = 240;     // u32 bounds: SR <= 4080 * 240*239/2 < 2^27
-    for (; u + UNROLL <= u_hi; u += UNROLL) {
-        uint4 v[UNROLL];
+    const long long groups = (u_hi - u) / UNROLL;
+    if (groups > 0) {
+        uint4 bufA[UNROLL], bufB[UNROLL];
+        auto request = [&](uint4 (&buf)[UNROLL], long long at) {
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j)
-            v[j] = *reinterpret_cast<const uint4 *>(args.a0 + off + (long long)j * kUnitBytes);
-        if constexpr (COPY) {
+            for (int j = 0; j < UNROLL; ++j) buf[j] = ld_stream(args.a0 + at + (long long)j * kUnitBytes);
+        };
+        auto retire = [&](uint4 (&buf)[UNROLL]) {
+            if constexpr (COPY) {
 #pragma unroll
-            for (int j = 0; j < UNROLL; ++j)
-                *reinterpret_cast<uint4 *>(args.dst0 + off + (long long)j * kUnitBytes) = v[j];
+                for (int j = 0; j < UNROLL; ++j)
+                    *reinterpret_cast<uint4 *>(args.dst0 + off + (long long)j * kUnitBytes) = buf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < UNROLL; ++j) consume(buf[j]);
+            off += (long long)UNROLL * kUnitBytes;
+            if constexpr (DO_ADLER) {
+                batch += UNROLL;
+                if (batch >= BATCH_MAX) fold_adler(off - kUnitBytes);
+            }
+        };
+        const long long gstride = (long long)UNROLL * kUnitBytes;
+        request(bufA, off);
+        long long k = 0;
+        while (k + 2 < groups) {                           // steady state: no conditional loads, counted waits
+            request(bufB, off + gstride);                  // group k+1
+            __builtin_amdgcn_sched_barrier(0);
+            retire(bufA);                                  // group k (off advances by one group)
+            request(bufA, off + gstride);                  // group k+2
+            __builtin_amdgcn_sched_barrier(0);
+            retire(bufB);
+            k += 2;
         }
-#pragma unroll
-        for (int j = 0; j < UNROLL; ++j) consume(v[j]);
-        off += (long long)UNROLL * kUnitBytes;
-        if constexpr (DO_ADLER) {
-            batch += UNROLL;
-            if (batch >= BATCH_MAX) fold_adler(off - kUnitBytes);
+        if (groups - k == 2) {
+            request(bufB, off + gstride);
+            __builtin_amdgcn_sched_barrier(0);
+            retire(bufA);
+            retire(bufB);
+        } else {
+            retire(bufA);
         }
+        u += groups * UNROLL;
     }
     for (; u < u_hi; ++u) {
         uint4 v = *reinterpret_cast<const uint4 *>(args.a0 + off);
@@ -186,8 +222,19 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     uint32_t pc = 0;
     if constexpr (DO_CRC) {
         if (u_hi > u_lo) {
-            const uint32_t *lw = tabs->lane_weight[t];
-            pc = mulmod(s0, lw[0]) ^ mulmod(s1, lw[1]) ^ mulmod(s2, lw[2]) ^ mulmod(s3, lw[3]);
+            // four GF(2) multiplies by the lane weights, one rolled 32-step loop (keeps the register
+            // budget of the streaming loop free of this one-off epilogue)
+            const uint4 lw = *reinterpret_cast<const uint4 *>(tabs->lane_weight[t]);
+            uint32_t b0 = lw.x, b1 = lw.y, b2 = lw.z, b3 = lw.w;
+#pragma unroll 1
+            for (int i = 31; i >= 0; --i) {
+                pc ^= (b0 & (0u - ((s0 >> i) & 1u))) ^ (b1 & (0u - ((s1 >> i) & 1u))) ^
+                      (b2 & (0u - ((s2 >> i) & 1u))) ^ (b3 & (0u - ((s3 >> i) & 1u)));
+                b0 = (b0 >> 1) ^ (kCrcPoly & (0u - (b0 & 1u)));
+                b1 = (b1 >> 1) ^ (kCrcPoly & (0u - (b1 & 1u)));
+                b2 = (b2 >> 1) ^ (kCrcPoly & (0u - (b2 & 1u)));
+                b3 = (b3 >> 1) ^ (kCrcPoly & (0u - (b3 & 1u)));
+            }
         }
     }
     uint32_t pa = (uint32_t)accA, pb = (uint32_t)accB;
