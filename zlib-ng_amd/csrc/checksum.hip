@@ -75,19 +75,23 @@ template <bool DO_ADLER, bool DO_CRC, bool COPY>
 __global__ __launch_bounds__(kWgThreads)
 void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
     __shared__ uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
+    __shared__ uint32_t stage[DO_CRC ? 4 * 256 + 256 : 4];   // linear copy of the stride tables + the byte table
     __shared__ uint32_t red[3][kWgThreads / 64];
 
     const int t = threadIdx.x;
     const uint32_t rep = t & 31;
 
     if constexpr (DO_CRC) {
-        // 32768 dwords, lane-consecutive LDS writes; the 32 replicas of one entry are 32 adjacent dwords
-        const uint32_t *src = &tabs->stride_tab[0][0];
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            int idx = i * kWgThreads + t;
-            lut[idx] = src[idx >> 5];
+        // tables: HBM/L2 -> LDS once (5 KiB, one dwordx4 per lane), then replicated LDS -> LDS:
+        // 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent dwords
+        if (t < 256) {
+            reinterpret_cast<uint4 *>(stage)[t] = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
+        } else if (t < 320) {
+            reinterpret_cast<uint4 *>(stage)[t] = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
         }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) lut[i * kWgThreads + t] = stage[i * 32 + (t >> 5)];
         __syncthreads();
     }
 
@@ -222,18 +226,22 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     uint32_t pc = 0;
     if constexpr (DO_CRC) {
         if (u_hi > u_lo) {
-            // four GF(2) multiplies by the lane weights, one rolled 32-step loop (keeps the register
-            // budget of the streaming loop free of this one-off epilogue)
-            const uint4 lw = *reinterpret_cast<const uint4 *>(tabs->lane_weight[t]);
-            uint32_t b0 = lw.x, b1 = lw.y, b2 = lw.z, b3 = lw.w;
+            // fold the four braids into one word located at the lane's last dword:
+            //   r = ((s0 * x^32 ^ s1) * x^32 ^ s2) * x^32 ^ s3, each x^32 = four byte-table steps (DO1 of
+            //   crc32_braid_p.h:58, the table sits in LDS), then ONE GF(2) multiply by that dword's weight.
+            const uint32_t *bt = stage + 1024;
+            uint32_t r = s0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r = bt[r & 0xffu] ^ (r >> 8);
+                r ^= c == 0 ? s1 : (c == 1 ? s2 : s3);
+            }
+            uint32_t b = tabs->lane_weight[t][3];
 #pragma unroll 1
             for (int i = 31; i >= 0; --i) {
-                pc ^= (b0 & (0u - ((s0 >> i) & 1u))) ^ (b1 & (0u - ((s1 >> i) & 1u))) ^
-                      (b2 & (0u - ((s2 >> i) & 1u))) ^ (b3 & (0u - ((s3 >> i) & 1u)));
-                b0 = (b0 >> 1) ^ (kCrcPoly & (0u - (b0 & 1u)));
-                b1 = (b1 >> 1) ^ (kCrcPoly & (0u - (b1 & 1u)));
-                b2 = (b2 >> 1) ^ (kCrcPoly & (0u - (b2 & 1u)));
-                b3 = (b3 >> 1) ^ (kCrcPoly & (0u - (b3 & 1u)));
+                pc ^= b & (0u - ((r >> i) & 1u));
+                b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));
             }
         }
     }
