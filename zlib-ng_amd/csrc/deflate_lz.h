@@ -66,6 +66,40 @@ __device__ __forceinline__ unsigned long long lz_bits_below(uint32_t b) {      /
     return b >= 64 ? ~0ull : ((1ull << b) - 1ull);
 }
 
+// common prefix of in[p..] and in[c..], counted from `from` (bytes below are known equal), capped at `cap`
+// and `maxlen`.  Eight dwords of each side are requested together, so one memory round trip covers 32 bytes.
+__device__ __forceinline__ uint32_t lz_common_prefix(const uint8_t *__restrict__ in, uint32_t p, uint32_t c,
+                                                     uint32_t from, uint32_t cap, uint32_t maxlen) {
+    uint32_t l = from;
+    while (l < cap) {
+        if (l + 32 <= maxlen) {
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = load_u32(in + p + l + 4 * k);
+                b[k] = load_u32(in + c + l + 4 * k);
+            }
+            int k = 0;
+#pragma unroll
+            for (int j = 7; j >= 0; --j)
+                if (a[j] != b[j]) k = j - 8;            // lowest differing dword, encoded as j - 8 (< 0)
+            if (k < 0) {
+                const int j = k + 8;
+                uint32_t x = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q == j) x = a[q] ^ b[q];
+                return l + 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x) - 1) >> 3);
+            }
+            l += 32;
+        } else {
+            while (l < maxlen && in[p + l] == in[c + l]) ++l;
+            return l < cap ? l : (l < maxlen ? l : maxlen);
+        }
+    }
+    return l;
+}
+
 struct LzPick {
     uint32_t kind;        // 0 = nothing to emit here, 1 = literal, 2 = match
     uint32_t len, dist;
@@ -108,62 +142,66 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
 
     // 2. probe
     uint32_t len = 0, dist = 0;
+    const uint32_t maxlen = p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u;
     if constexpr (!CHAIN) {
         if (old) {
             const uint32_t c = old - 1u;
-            if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
-                const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
-                len = 4;
-                while (len < kLzProbe) {
-                    if (len + 4 <= maxlen) {
-                        const uint32_t x = load_u32(in + p + len) ^ load_u32(in + c + len);
-                        if (x) {
-                            len += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                            break;
-                        }
-                        len += 4;
-                    } else {
-                        while (len < maxlen && in[p + len] == in[c + len]) ++len;
-                        break;
-                    }
+            if (c < p && p - c <= kLzMaxDist) {
+                const uint32_t l = lz_common_prefix(in, p, c, 0, kLzProbe, maxlen);
+                if (l >= kLzMinMatch) {
+                    len = l;
+                    dist = p - c;
                 }
-                dist = p - c;
             }
         }
     } else {
-        if (old) {
-            const uint32_t maxlen = (n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch;
+        if (old && maxlen >= kLzMinMatch) {
             uint32_t c = old - 1u;
             uint32_t best = 3;                           // a match must reach WANT_MIN_MATCH to count
             uint32_t chain = max_chain;
-            while (c < p && p - c <= kLzMaxDist) {
-                // quick reject on the 4 bytes ending at `best` (they must all match to beat it) and on the first 4
-                if (best + 1 <= maxlen && load_u32(in + c + best - 3) == load_u32(in + p + best - 3) &&
-                    load_u32(in + c) == val) {
-                    uint32_t l = 4;
-                    while (l < kLzChainProbe) {
-                        if (l + 4 <= maxlen) {
-                            const uint32_t x = load_u32(in + p + l) ^ load_u32(in + c + l);
-                            if (x) {
-                                l += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                                break;
-                            }
-                            l += 4;
-                        } else {
-                            while (l < maxlen && in[p + l] == in[c + l]) ++l;
-                            break;
-                        }
+            bool done = false;
+            while (!done && c != kLzNone) {
+                // walk up to kGather links first (LDS only), then fetch every candidate's probe words at once:
+                // one memory round trip per kGather candidates instead of one per candidate
+                constexpr int kGather = 8;
+                uint32_t cand[kGather];
+                int nc = 0;
+#pragma unroll
+                for (int k = 0; k < kGather; ++k) {
+                    if (c == kLzNone || !(c < p && p - c <= kLzMaxDist) || chain == 0) {
+                        c = kLzNone;
+                        break;
                     }
-                    if (l > best) {
-                        best = l;
-                        dist = p - c;
-                        if (l >= kLzChainProbe || l >= maxlen) break;      // nice_match reached
+                    cand[k] = c;
+                    nc = k + 1;
+                    --chain;
+                    const uint32_t d = sh->prev[c & 32767u];
+                    c = (d == 0 || d > c) ? kLzNone : c - d;
+                }
+                // quick reject (match_tpl.h:141-173): the 4 bytes ending at `best` and the first 4 must agree
+                const uint32_t tail_off = best - 3;
+                const bool can_tail = best + 1 <= maxlen;
+                const uint32_t want_tail = can_tail ? load_u32(in + p + tail_off) : 0u;
+                uint32_t ct[kGather], cf[kGather];
+#pragma unroll
+                for (int k = 0; k < kGather; ++k) {
+                    ct[k] = cf[k] = 0;
+                    if (k < nc) {
+                        cf[k] = load_u32(in + cand[k]);
+                        ct[k] = can_tail ? load_u32(in + cand[k] + tail_off) : 0u;
                     }
                 }
-                if (--chain == 0) break;
-                const uint32_t d = sh->prev[c & 32767u];
-                if (d == 0 || d > c) break;
-                c -= d;
+#pragma unroll
+                for (int k = 0; k < kGather; ++k) {
+                    if (k < nc && !done && can_tail && cf[k] == val && ct[k] == want_tail) {
+                        const uint32_t l = lz_common_prefix(in, p, cand[k], 4, kLzChainProbe, maxlen);
+                        if (l > best) {
+                            best = l;
+                            dist = p - cand[k];
+                            if (l >= kLzChainProbe || l >= maxlen) done = true;     // nice_match reached
+                        }
+                    }
+                }
             }
             if (best >= kLzMinMatch) len = best;
         }
