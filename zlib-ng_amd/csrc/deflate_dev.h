@@ -21,9 +21,19 @@ constexpr uint32_t kStdMinMatch = 3, kStdMaxMatch = 258;
 constexpr uint32_t kMinLookahead = kStdMaxMatch + kStdMinMatch + 1;   // deflate.h:405
 
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+#define ZR_GLOBAL __attribute__((address_space(1)))
 
+// Window / input bytes always live in HBM: say so (pointers that come out of a descriptor struct are generic
+// to the compiler, which would otherwise emit flat_load_* and tie up lgkmcnt as well as vmcnt).
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *p) {
-    return *reinterpret_cast<const u32_unaligned *>(p);
+    return *(const ZR_GLOBAL u32_unaligned *)(p);
+}
+__device__ __forceinline__ u32x4_unaligned load_u128(const uint8_t *p) {
+    return *(const ZR_GLOBAL u32x4_unaligned *)(p);
+}
+__device__ __forceinline__ uint8_t load_u8(const uint8_t *p) {
+    return *(const ZR_GLOBAL uint8_t *)(p);
 }
 
 // insert_string.c:11-13 + insert_string_tpl.h:48-51 (HASH_SLIDE 16, HASH_MASK 0xffff)

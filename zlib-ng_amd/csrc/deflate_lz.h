@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t lz_extend_wave(const uint8_t *a, const uint8
     if (off + 4 <= rem) {
         x = load_u32(a + off) ^ load_u32(b + off);
     } else if (off < rem) {
-        for (uint32_t j = 0; off + j < rem; ++j) x |= (uint32_t)(a[off + j] ^ b[off + j]) << (8 * j);
+        for (uint32_t j = 0; off + j < rem; ++j) x |= (uint32_t)(load_u8(a + off + j) ^ load_u8(b + off + j)) << (8 * j);
     }
     const unsigned long long diff = __ballot(x != 0);
     if (diff == 0) return rem;
@@ -73,12 +73,13 @@ __device__ __forceinline__ uint32_t lz_common_prefix(const uint8_t *__restrict__
     uint32_t l = from;
     while (l < cap) {
         if (l + 32 <= maxlen) {
-            uint32_t a[8], b[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                a[k] = load_u32(in + p + l + 4 * k);
-                b[k] = load_u32(in + c + l + 4 * k);
-            }
+            // two unaligned dwordx4 loads per side: 32 bytes for two TA passes instead of eight
+            const u32x4_unaligned a0 = load_u128(in + p + l);
+            const u32x4_unaligned a1 = load_u128(in + p + l + 16);
+            const u32x4_unaligned b0 = load_u128(in + c + l);
+            const u32x4_unaligned b1 = load_u128(in + c + l + 16);
+            const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             int k = 0;
 #pragma unroll
             for (int j = 7; j >= 0; --j)
@@ -93,7 +94,7 @@ __device__ __forceinline__ uint32_t lz_common_prefix(const uint8_t *__restrict__
             }
             l += 32;
         } else {
-            while (l < maxlen && in[p + l] == in[c + l]) ++l;
+            while (l < maxlen && load_u8(in + p + l) == load_u8(in + c + l)) ++l;
             return l < cap ? l : (l < maxlen ? l : maxlen);
         }
     }
