@@ -35,12 +35,16 @@ struct SegJob {
     uint64_t       sel_off;   // selector index of stream position 0
 };
 
+constexpr int      kChainHashBits = 13;        // 32 KiB head + 64 KiB prev links per segment
 constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block
 constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
 
-__global__ __launch_bounds__(256)
+constexpr int kChainWaves = 8;                 // 512 lanes walk chains per segment: latency hiding comes from lanes
+constexpr int kChainBatch = 64 * kChainWaves;
+
+__global__ __launch_bounds__(kChainBatch)
 void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain) {
-    __shared__ LzShared<true> sh;
+    __shared__ LzShared<true, kChainHashBits> sh;
 
     const SegJob job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
@@ -48,20 +52,20 @@ void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel
     uint32_t *sel = sel_base + job.sel_off;
     const int t = threadIdx.x;
 
-    for (int i = t; i < (1 << kLzHashBits); i += 256) sh.head[i] = 0;
-    for (int i = t; i < 32768 / 2; i += 256) reinterpret_cast<uint32_t *>(sh.prev)[i] = 0;
+    for (int i = t; i < (1 << kChainHashBits); i += kChainBatch) sh.head[i] = 0;
+    for (int i = t; i < 32768 / 2; i += kChainBatch) reinterpret_cast<uint32_t *>(sh.prev)[i] = 0;
     if (t == 0) sh.cover = job.seg_start;
     __syncthreads();
 
     uint32_t P0 = job.seg_start > kPrime ? job.seg_start - kPrime : 0u;
-    P0 &= ~255u;
-    const uint32_t first = job.seg_start & ~255u;   // batch holding the first byte of the segment
+    P0 -= P0 % kChainBatch;
+    const uint32_t first = job.seg_start - job.seg_start % kChainBatch;   // batch holding the segment's first byte
     uint32_t val = P0 + (uint32_t)t + kLzMinMatch <= n ? load_u32(in + P0 + t) : 0u;
-    for (uint32_t P = P0; P < n; P += 256) {
-        const uint32_t pn = P + 256u + (uint32_t)t;
+    for (uint32_t P = P0; P < n; P += kChainBatch) {
+        const uint32_t pn = P + (uint32_t)kChainBatch + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n) ? load_u32(in + pn) : 0u;
         const bool prime = P < first;
-        const LzPick r = lz_batch<true>(in, n, P, val, &sh, t, max_chain, prime);
+        const LzPick r = lz_batch<true, kChainHashBits, kChainWaves>(in, n, P, val, &sh, t, max_chain, prime);
         const uint32_t p = P + (uint32_t)t;
         if (!prime && p >= job.seg_start && p < n) {
             uint32_t s = 0;
@@ -540,7 +544,7 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     ZR_HIP(hipMemcpyAsync(g_dyn.d_jobs, jobs.data(), nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
 
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain);
+    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel,

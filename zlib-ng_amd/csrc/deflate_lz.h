@@ -25,7 +25,6 @@
 
 namespace zr {
 
-constexpr int      kLzHashBits = 14;                          // 16384 x u32 = 64 KiB of LDS: two streams per CU
 constexpr uint32_t kLzMaxDist = 32768u - kMinLookahead;       // MAX_DIST(s)
 constexpr uint32_t kLzProbe = 32;                             // bytes compared per lane before the parse
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
@@ -33,17 +32,21 @@ constexpr uint32_t kLzNone = 0xffffffffu;
 
 constexpr uint32_t kLzChainProbe = 64;                        // chain mode: per-lane compare cap (= "nice" length)
 
-template <bool CHAIN>
+// HBITS: log2 of the head table.  The table is the LDS budget of a stream, and the number of streams a CU can
+// keep in flight is what hides the latency of this (serial-per-stream) code: measured on MI355X, 4096 x 1 MiB,
+// level-1 class: 14 bits (2 streams/CU) 33.5 GB/s ratio 1.950, 13 bits (4/CU) 47.7 GB/s ratio 1.934.
+template <bool CHAIN, int HBITS>
 struct LzShared {                    // LDS state of one stream
-    uint32_t head[1 << kLzHashBits];
+    uint32_t head[1 << HBITS];
     uint16_t prev[CHAIN ? 32768 : 2];  // CHAIN: distance from a position to the previous one with the same hash (0 = none);
                                      //        the `prev` links of insert_string_tpl.h:98-102, stored as deltas
-    uint32_t last_start[4];          // per region: start of its last token if that token is a match, else kLzNone
-    uint32_t exit_pos[4];            // per region: first position after its last token
+    uint32_t last_start[8];          // per region: start of its last token if that token is a match, else kLzNone
+    uint32_t exit_pos[8];            // per region: first position after its last token
     uint32_t cover;                  // bytes below this position are already produced (carried across batches)
 };
 
-__device__ __forceinline__ uint32_t lz_hash(uint32_t val) { return (val * 2654435761u) >> (32 - kLzHashBits); }
+template <int HBITS>
+__device__ __forceinline__ uint32_t lz_hash(uint32_t val) { return (val * 2654435761u) >> (32 - HBITS); }
 
 // number of equal leading bytes of a[0..rem) and b[0..rem), rem <= 256, all 64 lanes take part
 __device__ __forceinline__ uint32_t lz_extend_wave(const uint8_t *a, const uint8_t *b, uint32_t rem, int lane) {
@@ -112,18 +115,19 @@ struct LzPick {
 //                longest_match (match_tpl.h:129-268) with its end-of-best-match quick reject (:167-173), then a
 //                one-step lazy evaluation in the parse (a longer match at the next byte wins, cf. max_lazy 16 of
 //                deflate.c:163).  `insert_only` batches just enter their positions (dictionary priming).
-template <bool CHAIN>
+template <bool CHAIN, int HBITS, int NW = 4>   // NW = wavefronts per workgroup (batch = 64 * NW positions)
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
-                                           LzShared<CHAIN> *sh, int t, uint32_t max_chain = 0, bool insert_only = false) {
+                                           LzShared<CHAIN, HBITS> *sh, int t, uint32_t max_chain = 0,
+                                           bool insert_only = false) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
     const bool can = p + kLzMinMatch <= n;              // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
-    const uint32_t h = lz_hash(val);
+    const uint32_t h = lz_hash<HBITS>(val);
 
     // 1. insert, waves in position order
     uint32_t old = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         if (wave == w && can) old = atomicExch(&sh->head[h], p + 1u);
         __syncthreads();
     }
@@ -258,7 +262,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     // 3b. stitch: cover = first position not yet produced when this region starts
     uint32_t cover = sh->cover;
     uint32_t carry = cover;
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < NW; ++v) {
         if (v == wave) cover = carry;
         const uint32_t ls = sh->last_start[v], ex = sh->exit_pos[v];
         const uint32_t region_end = P + 64u * (uint32_t)(v + 1);

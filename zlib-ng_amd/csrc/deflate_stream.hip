@@ -25,6 +25,8 @@
 
 namespace zr {
 
+constexpr int kQuickHashBits = 12;      // 16 KiB head table: up to 8 streams in flight per CU (see deflate_lz.h)
+
 struct StreamJobDev {
     const uint8_t *in;
     uint8_t       *out;
@@ -38,7 +40,7 @@ struct StreamJobDev {
 // The next batch's input is prefetched while the current one is parsed.
 __global__ __launch_bounds__(256)
 void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
-    __shared__ LzShared<false> sh;
+    __shared__ LzShared<false, kQuickHashBits> sh;
 
     const StreamJobDev job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
@@ -46,7 +48,7 @@ void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
     uint32_t *sel = sel_base + job.sel_off;
     const int t = threadIdx.x;
 
-    for (int i = t; i < (1 << kLzHashBits); i += 256) sh.head[i] = 0;
+    for (int i = t; i < (1 << kQuickHashBits); i += 256) sh.head[i] = 0;
     if (t == 0) sh.cover = 0;
     __syncthreads();
 
@@ -54,7 +56,7 @@ void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
     for (uint32_t P = 0; P < n; P += 256) {
         const uint32_t pn = P + 256u + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
-        const LzPick r = lz_batch<false>(in, n, P, val, &sh, t);
+        const LzPick r = lz_batch<false, kQuickHashBits>(in, n, P, val, &sh, t);
         const uint32_t p = P + (uint32_t)t;
         if (p < n) {
             uint32_t s = 0;
