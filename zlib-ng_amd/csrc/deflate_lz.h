@@ -40,8 +40,8 @@ struct LzShared {                    // LDS state of one stream
     uint32_t head[1 << HBITS];
     uint16_t prev[CHAIN ? 32768 : 2];  // CHAIN: distance from a position to the previous one with the same hash (0 = none);
                                      //        the `prev` links of insert_string_tpl.h:98-102, stored as deltas
-    uint32_t last_start[8];          // per region: start of its last token if that token is a match, else kLzNone
-    uint32_t exit_pos[8];            // per region: first position after its last token
+    uint32_t last_start[16];         // per region: start of its last token if that token is a match, else kLzNone
+    uint32_t exit_pos[16];           // per region: first position after its last token
     uint32_t cover;                  // bytes below this position are already produced (carried across batches)
 };
 
