@@ -87,8 +87,8 @@ def pmc_traffic(kernel, nbytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=200)   # LDS-heavy kernels reach their steady clock after ~100 launches (tools/micro/fused_steady.py)
     ap.add_argument("--shard-mib", type=int, default=SHARD_BYTES >> 20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
