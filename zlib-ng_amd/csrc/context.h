@@ -23,6 +23,7 @@ struct DeviceTables {
                                          //   (same construction as tools/makecrct.c:99-112 with n*w = kUnitBytes)
     uint32_t lane_weight[kWgThreads][4]; // word c of lane t -> x^(8*(kUnitBytes - 16t - 4c)): distance to unit end
     uint32_t pow_tab[kPowDigits * 128];  // x^(8 * digit * 128^i), see gf2.h xpow_bytes
+    uint32_t unit_pow[2][1024];          // x^(8 * kUnitBytes * d * 1024^i): weight of "d units later", two 10-bit digits
 };
 
 struct Partial {            // one per workgroup, written by the streaming kernel
@@ -34,6 +35,7 @@ struct Partial {            // one per workgroup, written by the streaming kerne
 
 struct Workspace {          // one per HIP stream
     Partial  *partials;     // kMaxGroups entries
+    uint32_t *acc;          // {crc xor, adler A sum, adler B sum, ticket}: device-scope accumulators, zero between calls
     uint32_t *result;       // 2 x u32 scratch result (device)
     uint32_t *pinned;       // 2 x u32 host-pinned mirror
     uint8_t  *stage;        // device staging for host-pointer slots

@@ -61,6 +61,14 @@ static void build_tables(DeviceTables &t) {
                 cur = mulmod(cur, x32);
             }
     }
+    for (int i = 0; i < 2; ++i) {
+        uint32_t step = xpow_bits(8ull * (uint64_t)kUnitBytes << (10 * i));   // x^(8 * U * 1024^i)
+        uint32_t cur = 0x80000000u;
+        for (int d = 0; d < 1024; ++d) {
+            t.unit_pow[i][d] = cur;
+            cur = mulmod(cur, step);
+        }
+    }
     for (int i = 0; i < kPowDigits; ++i) {
         uint32_t step = xpow_bits(8ull << (7 * i));      // x^(8 * 128^i)
         uint32_t cur = 0x80000000u;                      // digit 0 -> x^0
@@ -96,6 +104,7 @@ Workspace *workspace_for(hipStream_t s) {
     memset(ws, 0, sizeof(*ws));
     if (hipMalloc(&ws->partials, sizeof(Partial) * kMaxGroups) != hipSuccess ||
         hipMalloc(&ws->result, 64) != hipSuccess ||
+        hipMalloc(&ws->acc, 64) != hipSuccess || hipMemset(ws->acc, 0, 64) != hipSuccess ||
         hipHostMalloc(&ws->pinned, 64, hipHostMallocDefault) != hipSuccess) {
         set_error("workspace allocation failed");
         delete ws;
