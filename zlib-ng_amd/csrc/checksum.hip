@@ -25,9 +25,10 @@
 //          are applied in closed form, B = sum (n - pos) * byte, so blocks combine by plain addition
 //          (the linear form of adler32_combine_).
 // Each workgroup weights its CRC partial to the end of the body (x^(8 * 16 KiB * units_after), two table
-// multiplies) and adds {crc, A, B} into device-scope accumulators; a ticket counter tells the LAST group to
-// arrive, which folds the tail bytes and the seed and writes the checksum(s) to device memory -- one launch
-// per call.  (Messages shorter than one granule take the small finalize kernel alone.)
+// multiplies) and leaves one Partial; the small finalize kernel XORs / sums them, folds the tail bytes and
+// the seed (whose image ~seed * x^(8n) the host evaluates) and writes the checksum(s) to device memory.
+// (A single-launch variant -- device-scope accumulators + arrival ticket -- was measured and rejected: the
+// dependent device-scope atomics cost ~6 us per call, more than the 3-4 us of the second launch.)
 #include "context.h"
 
 namespace zr {
@@ -70,14 +71,6 @@ struct StreamArgs {
     long long      nunits;    // ceil(body / kUnitBytes)
     int            head;      // buf - a0, 0..15
     int            tail;      // bytes of the message living in the granule at tail_base
-    // fused finalize: the last workgroup to arrive (device-scope ticket) turns the accumulators into the result
-    uint32_t      *acc;       // {crc xor, adler A, adler B, ticket}, all zero on entry and on exit
-    const uint8_t *tail_base; // granule with the < 16 trailing bytes, valid bytes [tail_lo, tail_hi)
-    uint8_t       *tail_dst;  // COPY: where they go
-    int            tail_lo, tail_hi;
-    uint32_t       adler_seed;
-    uint32_t       crc_seed_term;   // ~seed * x^(8n), evaluated on the host (a handful of table multiplies)
-    uint32_t      *out_adler, *out_crc;
 };
 
 // DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
@@ -288,57 +281,12 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
                 if (k >> 10) c = mulmod(c, tabs->unit_pow[1][(k >> 10) & 1023u]);
             }
         }
-        // Device-scope accumulation: XOR and + are commutative, so arrival order does not matter.  The
-        // returning ticket add is issued only after the three updates are acknowledged (vmcnt(0)).
-        if constexpr (DO_CRC) atomicXor(&args.acc[0], c);
-        if constexpr (DO_ADLER) {
-            atomicAdd(&args.acc[1], (uint32_t)(a % kAdlerBase));
-            atomicAdd(&args.acc[2], (uint32_t)(b % kAdlerBase));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t ticket = atomicAdd(&args.acc[3], 1u);
-        red[0][0] = ticket == (uint32_t)gridDim.x - 1u;
-    }
-    (void)partials;
-    __syncthreads();
-    if (!red[0][0] || t >= 64) return;
-
-    // ---- last group, first wave: tail bytes, seed, result -------------------------------------------------
-    const int ntail = args.tail_hi - args.tail_lo;
-    uint32_t tc = 0;
-    unsigned long long ta = 0, tb = 0;
-    if (t < ntail) {
-        const uint32_t byte = args.tail_base[args.tail_lo + t];
-        if constexpr (COPY) args.tail_dst[args.tail_lo + t] = (uint8_t)byte;
-        const int after = ntail - 1 - t;                          // message bytes behind this one
-        if constexpr (DO_CRC) tc = mulmod(tabs->byte_tab[byte], tabs->pow_tab[after]);
-        ta = byte;
-        tb = (unsigned long long)byte * (unsigned)(after + 1);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        tc ^= __shfl_xor(tc, m, 64);
-        ta += __shfl_xor(ta, m, 64);
-        tb += __shfl_xor(tb, m, 64);
-    }
-    if (t == 0) {
-        // exchange = read and reset in one device-scope operation (the accumulators are zero for the next call)
-        const uint32_t C = atomicExch(&args.acc[0], 0u);
-        const unsigned long long A = atomicExch(&args.acc[1], 0u);
-        const unsigned long long B = atomicExch(&args.acc[2], 0u);
-        atomicExch(&args.acc[3], 0u);
-        if constexpr (DO_ADLER) {
-            // seed halves are masked, not reduced (adler32_c.c:16-17); s1' = s1 + A, s2' = s2 + n*s1 + B
-            const unsigned long long s1 = args.adler_seed & 0xffffu, s2 = (args.adler_seed >> 16) & 0xffffu;
-            const unsigned long long n_mod = (unsigned long long)args.n % kAdlerBase;
-            const unsigned long long r1 = (s1 + A + ta) % kAdlerBase;
-            const unsigned long long r2 = (s2 + n_mod * s1 + B + tb % kAdlerBase) % kAdlerBase;
-            *args.out_adler = (uint32_t)(r1 | (r2 << 16));
-        }
-        if constexpr (DO_CRC) {
-            const uint32_t body = ntail ? mulmod(C, tabs->pow_tab[ntail]) : C;
-            *args.out_crc = ~(body ^ tc ^ args.crc_seed_term);
-        }
+        Partial pt;
+        pt.crc = c;                                   // already weighted to the end of the body
+        pt.a = (uint32_t)(a % kAdlerBase);
+        pt.b = (uint32_t)(b % kAdlerBase);
+        pt.pad = 0;
+        partials[g] = pt;
     }
 }
 
@@ -351,7 +299,7 @@ struct FinalArgs {
     int            tail_hi;
     int            groups;
     uint32_t       adler_seed;
-    uint32_t       crc_seed;
+    uint32_t       crc_seed_term;   // ~seed * x^(8n), evaluated on the host (a handful of table multiplies)
     int            do_adler, do_crc;
 };
 
@@ -361,37 +309,37 @@ void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const 
     __shared__ uint32_t red[3][4];
     const int t = threadIdx.x;
     const long long G = fa.groups;
-    const long long q = fa.nunits / G, r = fa.nunits % G;
     const int ntail = fa.tail_hi - fa.tail_lo;
 
     uint32_t c = 0;
     unsigned long long a = 0, b = 0;
     for (long long g = t; g < G; g += blockDim.x) {
         Partial p = partials[g];
-        long long u_hi = g * q + (g < r ? g : r) + q + (g < r ? 1 : 0);
-        if (fa.do_crc && p.crc) {
-            unsigned long long after = (unsigned long long)(fa.nunits - u_hi) * kUnitBytes + (unsigned long long)ntail;
-            c ^= mulmod(p.crc, xpow_bytes(tabs->pow_tab, after));
-        }
+        c ^= p.crc;                                  // weighted to the end of the body by its workgroup
         a += p.a;
         b += p.b;
     }
-    // trailing (< 16) bytes: one lane each
+    // trailing (< 16) bytes: one lane each; kept apart from the body sum, which still has to be advanced
+    // over them (one multiply, by lane 0 at the end)
+    uint32_t tc = 0;
     if (t < ntail) {
         uint32_t byte = fa.tail_base[fa.tail_lo + t];
         if (fa.tail_dst) fa.tail_dst[fa.tail_lo + t] = (uint8_t)byte;
         int after = ntail - 1 - t;                  // message bytes behind this one
-        if (fa.do_crc) c ^= mulmod(tabs->byte_tab[byte], tabs->pow_tab[after]);
+        if (fa.do_crc) tc = mulmod(tabs->byte_tab[byte], tabs->pow_tab[after]);
         a += byte;
         b += (unsigned long long)byte * (unsigned)(after + 1);
     }
+    __shared__ uint32_t red_t[4];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         c ^= __shfl_xor(c, m, 64);
+        tc ^= __shfl_xor(tc, m, 64);
         a += __shfl_xor(a, m, 64);
         b += __shfl_xor(b, m, 64);
     }
     if ((t & 63) == 0) {
+        red_t[t >> 6] = tc;
         red[0][t >> 6] = c;
         red[1][t >> 6] = (uint32_t)(a % kAdlerBase);
         red[2][t >> 6] = (uint32_t)(b % kAdlerBase);
@@ -410,9 +358,9 @@ void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const 
             *out_adler = (uint32_t)(r1 | (r2 << 16));
         }
         if (fa.do_crc) {
-            // register started at ~seed: its image after n bytes is ~seed * x^(8n)
-            uint32_t init = mulmod(~fa.crc_seed, xpow_bytes(tabs->pow_tab, (unsigned long long)fa.n));
-            *out_crc = ~(cc ^ init);
+            // body advanced over the tail bytes, tail terms, and the seed's image ~seed * x^(8n) (host-evaluated)
+            const uint32_t body = (ntail && cc) ? mulmod(cc, tabs->pow_tab[ntail]) : cc;
+            *out_crc = ~(body ^ red_t[0] ^ red_t[1] ^ red_t[2] ^ red_t[3] ^ fa.crc_seed_term);
         }
     }
 }
@@ -470,21 +418,12 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     fa.tail_hi = sa.tail;
     if (len == 0) fa.tail_lo = fa.tail_hi = 0;
     fa.adler_seed = adler;
-    fa.crc_seed = crc;
+    fa.crc_seed_term = do_crc ? mulmod(~crc, xpow_bytes(c->host_tables.pow_tab, (uint64_t)len)) : 0u;
     fa.do_adler = do_adler;
     fa.do_crc = do_crc;
 
     const int groups = pick_groups(c, sa.nunits);
     fa.groups = groups;
-    sa.acc = ws->acc;
-    sa.tail_base = fa.tail_base;
-    sa.tail_dst = fa.tail_dst;
-    sa.tail_lo = fa.tail_lo;
-    sa.tail_hi = fa.tail_hi;
-    sa.adler_seed = adler;
-    sa.crc_seed_term = do_crc ? mulmod(~crc, xpow_bytes(c->host_tables.pow_tab, (uint64_t)len)) : 0u;
-    sa.out_adler = d_out_adler;
-    sa.out_crc = d_out_crc;
     if (sa.nunits > 0) {
         dim3 grid(groups), block(kWgThreads);
         trace_mark(stream, true);
@@ -502,10 +441,9 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
 #undef ZR_LAUNCH
         trace_mark(stream, false);
         ZR_HIP(hipGetLastError());
-        return ZNG_ROCM_OK;             // the last workgroup of the streaming kernel wrote the result
+    } else {
+        ZR_HIP(hipMemsetAsync(ws->partials, 0, sizeof(Partial) * groups, stream));
     }
-    // fewer than 16 bytes inside one granule: no body, the small finalize kernel does everything
-    ZR_HIP(hipMemsetAsync(ws->partials, 0, sizeof(Partial) * groups, stream));
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, fa, c->tables, ws->partials,
                        d_out_adler, d_out_crc);
     ZR_HIP(hipGetLastError());
