@@ -229,6 +229,25 @@ int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, cons
 int  zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                           void *stream);
 
+/* as zng_rocm_inflate_raw, also reporting how many input bytes the deflate stream occupied */
+int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
+                             size_t *in_used, void *stream);
+
+/* ---- compress2 / uncompress2 class front ends (compress.c:31-98, uncompr.c:25-76) ---------------------
+ * `format`: 0 = raw deflate, 1 = zlib (RFC 1950), 2 = gzip (RFC 1952).  The trailer checksum (Adler-32 /
+ * CRC-32 + ISIZE) is computed by the device checksum kernel over the device-resident plaintext.
+ * compress2_dev:   d_src (device) -> d_dst (device, *dst_len >= zng_rocm_compress_bound()); level as compress2
+ *                  (-1 = 6; levels below 2 use the level-2 matcher).  Returns Z_OK (0) / Z_BUF_ERROR (-5) / error.
+ * uncompress2_dev: src (HOST, the sequential bitstream stays on the host) -> d_dst (device).  On return *dst_len
+ *                  = plaintext bytes, *src_len = input bytes consumed.  Z_OK, Z_BUF_ERROR (destination too small),
+ *                  Z_DATA_ERROR with the reference's message text in zng_rocm_last_error() ("incorrect header
+ *                  check", "incorrect data check", "incorrect length check", decoder messages, incomplete stream). */
+size_t zng_rocm_compress_bound(size_t source_len, int format);
+int    zng_rocm_compress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *d_src, size_t src_len, int level,
+                              int format, void *stream);
+int    zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *src, size_t *src_len, int format,
+                                void *stream);
+
 /* ---- measurement hooks --------------------------------------------------
  * Between trace_begin and trace_end every launch of the DOMINANT kernel of a
  * *_dev entry point (the streaming kernel, not its finalize step) is bracketed

@@ -133,8 +133,17 @@ int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const
     return ZNG_ROCM_OK;
 }
 
+int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
+                            size_t *in_used, void *stream);
+
 int zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                          void *stream) {
+    return zng_rocm_inflate_raw_ex(src, src_len, d_dst, dst_cap, out_len, nullptr, stream);
+}
+
+// same, also reporting how many input bytes the stream occupied (the framing front ends find the trailer there)
+int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
+                            size_t *in_used, void *stream) {
     if (!ctx()) {
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
@@ -143,6 +152,7 @@ int zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, siz
     zng_rocm_inflate_tokens tk;
     int status = zng_rocm_inflate_tokens_decode(src, src_len, &tk);
     if (out_len) *out_len = tk.out_len;
+    if (in_used) *in_used = tk.in_used;
     if (status == -4) {
         zng_rocm_inflate_tokens_free(&tk);
         return ZNG_ROCM_ENOMEM;

@@ -71,6 +71,13 @@ _PROTOS = {
                                                C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "zng_rocm_inflate_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                        C.c_void_p]),
+    "zng_rocm_inflate_raw_ex": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_size_t), C.c_void_p]),
+    "zng_rocm_compress_bound": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "zng_rocm_compress2_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_void_p]),
+    "zng_rocm_uncompress2_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                                           C.c_int, C.c_void_p]),
     "zng_rocm_trace_begin": (C.c_int, [C.c_int]),
     "zng_rocm_trace_end": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "zng_rocm_adler32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
