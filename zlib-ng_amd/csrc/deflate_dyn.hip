@@ -22,6 +22,7 @@
 #include "deflate_dev.h"
 #include "deflate_lz.h"
 
+#include <mutex>
 #include <vector>
 
 namespace zr {
@@ -463,6 +464,7 @@ struct DynScratch {
     uint64_t *d_dst_off = nullptr;
 };
 static DynScratch g_dyn;
+static std::mutex g_scratch_mu;      // the scratch buffers are process-wide: one deflate call at a time
 
 static inline size_t seg_slot_bytes(uint32_t n) {
     // <= 9 bits per literal for an almost flat alphabet, + header (< 400 bytes) + trailer; 4-byte aligned
@@ -499,6 +501,7 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         set_error("out_cap below zng_rocm_deflate_bound()");
         return -5;
     }
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
     hipStream_t st = (hipStream_t)stream;
     // max_chain_length per level, deflate.c:142-168
     static const uint32_t chains[10] = {0, 4, 4, 6, 24, 32, 128, 256, 1024, 4096};

@@ -21,6 +21,7 @@
 #include "deflate_lz.h"
 
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 namespace zr {
@@ -248,6 +249,7 @@ struct DeflateScratch {
     size_t        sel_cap = 0;
 };
 static DeflateScratch g_ds;
+static std::mutex g_scratch_mu;      // the scratch buffers are process-wide: one deflate call at a time
 
 }  // namespace zr
 
@@ -270,6 +272,7 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     if (!njobs) return ZNG_ROCM_OK;
     if (!jobs || !d_results) return ZNG_ROCM_EINVAL;
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
     hipStream_t st = (hipStream_t)stream;
     if (njobs > g_ds.job_cap) {
         if (g_ds.d_jobs) (void)hipFree(g_ds.d_jobs);
