@@ -84,6 +84,93 @@ def pmc_traffic(kernel, nbytes):
     return best
 
 
+def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse):
+    """BASELINE.json configs[4]: `--streams` independent 1 MiB streams, level-1 class, sharded over the ranks
+    (strong scaling: the total is fixed).  Step = every rank compresses its shard (K1 parse + K2 static emit) and
+    the {clen, adler32, ulen} table is all-gathered (RCCL, 24 bytes per stream) and prefix-summed on every rank."""
+    import zlib
+
+    import numpy as np
+    import synth
+    dfl = importlib.import_module("zlib-ng_amd.deflate")
+    each = 1 << 20
+    first, count = par.shard_streams(args.streams, world, rank)
+    # stream i = slice (i mod 96) of a 96 MiB six-class mix (seed 0x5EED0005): every rank can rebuild any stream
+    base = synth.silesia_like(96 << 20, seed=0x5EED0005, seg_bytes=1 << 20)
+    idx = (np.arange(first, first + count) % 96)
+    host = np.concatenate([base[i * each:(i + 1) * each] for i in idx]) if count else np.zeros(16, dtype=np.uint8)
+    src = torch.from_numpy(host).to(dev)
+    batch = dfl.QuickBatch(src, [i * each for i in range(count)], [each] * count)
+    ulen = torch.full((count,), each, dtype=torch.int64, device=dev)
+    state = {}
+
+    def step():
+        batch.run()
+        res = batch.results.to(torch.int64) & 0xffffffff
+        local = torch.stack([res[:, 0], res[:, 1], ulen], dim=1) if count else torch.zeros((0, 3), dtype=torch.int64, device=dev)
+        if world > 1:
+            tab = local.cpu() if rehearse else local
+            state["table"] = par.gather_stream_table(tab, args.streams)
+        else:
+            state["table"] = (local, torch.cumsum(local[:, 0], 0) - local[:, 0], None)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    fence()
+    zr.trace_begin(args.steps)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = zr.trace_end(args.steps)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    table = state["table"][0].cpu()
+    # parity on this rank: first and last local stream round-trip through an independent inflater
+    res = batch.results.cpu()
+    for i in ([0, count - 1] if count else []):
+        assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == host[i * each:(i + 1) * each].tobytes()
+    if rank == 0:
+        total_in = args.streams * each
+        total_out = int(table[:, 0].sum())
+        k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
+        local_bytes = count * each + int(res[:, 0].to(torch.int64).sum())
+        line = {
+            "metric": METRIC, "value": round(total_in / 1e9 / (elapsed / args.steps), 2), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[4]: %d independent 1 MiB streams, deflate level-1 class (static Huffman), "
+                                   "sharded %d-way, {clen, adler32, ulen} table all-gathered" % (args.streams, world),
+                       "streams_per_gpu": count, "ratio": round(total_in / total_out, 3),
+                       "parallelism": "streams/%d+allgather(24B/stream)" % world, "rehearsal_same_gpu": rehearse},
+            "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (latency bound: serial-per-stream LZ77 front end)",
+                         "achieved": round(local_bytes / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
+        }
+        if not args.no_cpu:
+            t0 = time.perf_counter()
+            done = 0
+            while time.perf_counter() - t0 < 10 and done < count:
+                zlib.compress(host[done * each:(done + 1) * each].tobytes(), 1)
+                done += 1
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(done * each / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                                    "sample": "%d of this rank's streams through CPython zlib level 1 (classic zlib 1.2.11, "
+                                              "an independent codec: zlib-ng itself cannot be built here), one thread" % done}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +178,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)   # LDS-heavy kernels reach their steady clock after ~100 launches (tools/micro/fused_steady.py)
     ap.add_argument("--shard-mib", type=int, default=SHARD_BYTES >> 20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workload", choices=("checksum", "streams"), default="checksum",
+                    help="checksum = BASELINE.json configs[1] (default, the driver's contract); "
+                         "streams = configs[4]: 4096 x 1 MiB level-1 class deflate sharded over the ranks")
+    ap.add_argument("--streams", type=int, default=4096)
     args = ap.parse_args()
 
     import numpy as np
@@ -119,6 +210,13 @@ def main():
     zr = importlib.import_module("zlib-ng_amd")      # raises if libzng_rocm.so is missing: no fallback
     zr.init(local_rank)
     par = importlib.import_module("zlib-ng_amd.parallel")
+
+    if args.workload == "streams":
+        run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n = args.shard_mib << 20
     gen = torch.Generator(device=dev)
