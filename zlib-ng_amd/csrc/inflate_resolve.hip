@@ -6,62 +6,119 @@
 //   K1 segments  one wavefront per >=128 KiB output segment walks its tokens in order and writes 16-bit
 //                SYMBOLS: a literal byte, or 256 + k meaning "byte k of the 32 KiB that precede this
 //                segment".  Copies inside the segment move symbols, so unresolved references
-//                propagate by themselves; no segment waits for another.
+//                propagate by themselves; no segment waits for another.  The wave's last 4096 symbols
+//                live in an LDS ring (the device form of inflate's sliding window, inflate.c:325-378).
 //   K2 context   one workgroup walks the segments in order and finalises only the last 32 KiB of each
 //                (the only bytes a later segment can name) -- 32 KiB per step instead of the whole stream.
 //   K3 translate all symbols -> bytes, fully parallel: 2N read + N written, HBM-bound.
 //
 // Algorithmic bytes: C + U per stream; the symbol detour adds 4U of HBM traffic.
 #include "context.h"
+#include "deflate_dev.h"
 
 namespace zr {
 
-constexpr long long kCtx = 32768;         // MAX_WBITS 15: a distance never exceeds this
+constexpr long long kCtx = 32768;        // MAX_WBITS 15: a distance never exceeds this
+
+// K1.  One wavefront per segment, four per workgroup.  Per wave in LDS: a ring with the last 4096 symbols it
+// produced (recent back-references never touch HBM, and a match no longer waits for the wave's own stores to
+// be acknowledged), a 1 KiB window of upcoming literal bytes, and the tokens 64 at a time in registers.
+// Symbols leave the ring in coalesced 2048-symbol flushes; a source below `flushed` is read back from HBM.
+constexpr int kRing = 4096;               // symbols per wave (8 KiB)
+constexpr int kFlush = 2048;
+constexpr int kLitWin = 1024;
 
 __global__ __launch_bounds__(256)
 void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t *__restrict__ literals,
-                             const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
+                             size_t nliterals, const uint64_t *__restrict__ segs, size_t nsegs,
+                             uint16_t *__restrict__ sym) {
+    __shared__ uint16_t ring_all[4][kRing];
+    __shared__ uint8_t lit_all[4][kLitWin];
     const int lane = threadIdx.x & 63;
-    const size_t seg = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int w = threadIdx.x >> 6;
+    const size_t seg = (size_t)blockIdx.x * 4 + (size_t)w;
     if (seg >= nsegs) return;
+    uint16_t *ring = ring_all[w];
+    uint8_t *lit = lit_all[w];
     const uint64_t t0 = segs[3 * seg], t1 = segs[3 * seg + 3];
     const long long o0 = (long long)segs[3 * seg + 1];
-    long long op = o0;
+    long long op = o0, flushed = o0;
     unsigned long long lp = segs[3 * seg + 2];
+    unsigned long long lit_base = lp;
     const long long ctx_base = o0 - kCtx;
 
-    for (uint64_t t = t0; t < t1; ++t) {
-        const uint32_t tok = tokens[t];
-        if (!(tok >> 31)) {
-            const uint32_t n = tok;
-            for (uint32_t i = (uint32_t)lane; i < n; i += 64) sym[op + i] = literals[lp + i];
-            op += n;
-            lp += n;
+    auto stage_literals = [&]() {            // lit[] <- literals[lit_base .. lit_base + kLitWin)
+        const unsigned long long at = lit_base + 16ull * (unsigned long long)lane;
+        if (at + 16 <= nliterals) {
+            const u32x4_unaligned v = load_u128(literals + at);           // one unaligned dwordx4 per lane
+            *reinterpret_cast<uint4 *>(lit + 16 * lane) = make_uint4(v.x, v.y, v.z, v.w);
         } else {
-            const uint32_t len = ((tok >> 16) & 0xffu) + 3u;
-            const uint32_t dist = (tok & 0xffffu) + 1u;
-            const long long src = op - (long long)dist;
-            // everything this wave stored so far must be readable
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_s_waitcnt(0);
-            uint16_t v[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                v[k] = 0;
-                if (i < len) {
-                    const long long p = src + (long long)(dist < len ? i % dist : i);
-                    v[k] = p >= o0 ? sym[p] : (uint16_t)(256 + (p - ctx_base));
+            for (int k = 0; k < 16; ++k) {
+                const unsigned long long q = at + (unsigned long long)k;
+                lit[16 * lane + k] = q < nliterals ? literals[q] : 0;
+            }
+        }
+    };
+    auto flush = [&](long long upto) {       // symbols [flushed, upto) ring -> HBM, coalesced
+        for (long long i = flushed + lane; i < upto; i += 64) sym[i] = ring[i & (kRing - 1)];
+        flushed = upto;
+        // a later match may read these symbols back from HBM: have the stores acknowledged first
+        // (once per 2048 symbols, not once per token)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);
+    };
+
+    stage_literals();
+    for (uint64_t base = t0; base < t1; base += 64) {
+        const uint32_t mytok = base + (uint64_t)lane < t1 ? tokens[base + lane] : 0u;
+        const int cnt = (int)((t1 - base) < 64 ? (t1 - base) : 64);
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)mytok, j);
+            if (!(tok >> 31)) {
+                uint32_t n = tok;
+                while (n) {
+                    if (op - flushed >= kFlush) flush(flushed + kFlush);
+                    uint32_t avail = (uint32_t)(lit_base + kLitWin - lp);
+                    if (avail == 0) {
+                        lit_base = lp;
+                        stage_literals();
+                        avail = kLitWin;
+                    }
+                    const uint32_t chunk = n < avail ? n : avail;
+                    const uint32_t lo = (uint32_t)(lp - lit_base);
+                    for (uint32_t i = (uint32_t)lane; i < chunk; i += 64)
+                        ring[(op + i) & (kRing - 1)] = lit[lo + i];
+                    op += chunk;
+                    lp += chunk;
+                    n -= chunk;
                 }
-            }
+            } else {
+                if (op - flushed >= kFlush) flush(flushed + kFlush);
+                const uint32_t len = ((tok >> 16) & 0xffu) + 3u;
+                const uint32_t dist = (tok & 0xffffu) + 1u;
+                const long long src = op - (long long)dist;
+                uint16_t v[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                if (i < len) sym[op + i] = v[k];
+                for (int k = 0; k < 5; ++k) {
+                    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                    v[k] = 0;
+                    if (i < len) {
+                        const long long p = src + (long long)(dist < len ? i % dist : i);
+                        if (p >= flushed) v[k] = ring[p & (kRing - 1)];
+                        else if (p >= o0) v[k] = sym[p];
+                        else v[k] = (uint16_t)(256 + (p - ctx_base));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+                    if (i < len) ring[(op + i) & (kRing - 1)] = v[k];
+                }
+                op += len;
             }
-            op += len;
         }
     }
+    flush(op);
 }
 
 // One workgroup; segment s (s >= 0) gets the last 32 KiB of its output finalised, in order.
@@ -116,12 +173,11 @@ int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const
         return ZNG_ROCM_ENODEV;
     }
     (void)ntokens;
-    (void)nliterals;
     if (out_len == 0 || nsegs == 0) return ZNG_ROCM_OK;
     if (!d_tokens || !d_segs || !d_symbols || !d_out) return ZNG_ROCM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(inflate_segments_kernel, dim3((unsigned)((nsegs + 3) / 4)), dim3(256), 0, st, d_tokens,
-                       d_literals, d_segs, nsegs, d_symbols);
+                       d_literals, nliterals, d_segs, nsegs, d_symbols);
     ZR_HIP(hipGetLastError());
     if (nsegs > 1) {
         hipLaunchKernelGGL(inflate_context_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, d_symbols, d_out);
