@@ -121,19 +121,31 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
     flush(op);
 }
 
-// One workgroup; segment s (s >= 0) gets the last 32 KiB of its output finalised, in order.
+// K2.  One workgroup; segment s (s >= 0) gets the last 32 KiB of its output finalised, in order.  Each lane owns
+// 32 symbols of the 32 KiB; all its loads are issued before any is used, so one step costs a few memory round
+// trips (symbol loads, context gathers, stores) instead of 32 dependent ones.
 __global__ __launch_bounds__(1024)
 void inflate_context_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
                             uint8_t *__restrict__ out) {
+    constexpr int PER = (int)(kCtx / 1024);            // 32
     for (size_t s = 0; s + 1 < nsegs; ++s) {
         const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
         long long lo = o1 - kCtx;
         if (lo < o0) lo = o0;
         const long long ctx_base = o0 - kCtx;
-        for (long long i = lo + threadIdx.x; i < o1; i += blockDim.x) {
-            uint16_t v = sym[i];
-            if (v >= 256) v = out[ctx_base + (v - 256)];
-            out[i] = (uint8_t)v;
+        uint16_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const long long i = lo + threadIdx.x + 1024LL * k;
+            v[k] = i < o1 ? sym[i] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (v[k] >= 256) v[k] = out[ctx_base + (v[k] - 256)];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const long long i = lo + threadIdx.x + 1024LL * k;
+            if (i < o1) out[i] = (uint8_t)v[k];
         }
         __threadfence_block();
         __syncthreads();
