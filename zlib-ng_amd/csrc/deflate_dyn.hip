@@ -46,7 +46,8 @@ constexpr int kChainWaves = 16;                // 1024 lanes walk chains per seg
 constexpr int kChainBatch = 64 * kChainWaves;
 
 __global__ __launch_bounds__(kChainBatch)
-void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain) {
+void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain,
+                     uint32_t good_match) {
     __shared__ LzShared<true, kChainHashBits> sh;
 
     const SegJob job = jobs[blockIdx.x];
@@ -68,7 +69,7 @@ void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel
         const uint32_t pn = P + (uint32_t)kChainBatch + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n) ? load_u32(in + pn) : 0u;
         const bool prime = P < first;
-        const LzPick r = lz_batch<true, kChainHashBits, kChainWaves>(in, n, P, val, &sh, t, max_chain, prime);
+        const LzPick r = lz_batch<true, kChainHashBits, kChainWaves>(in, n, P, val, &sh, t, max_chain, prime, good_match);
         const uint32_t p = P + (uint32_t)t;
         if (!prime && p >= job.seg_start && p < n) {
             uint32_t s = 0;
@@ -507,6 +508,8 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     static const uint32_t chains[10] = {0, 4, 4, 6, 24, 32, 128, 256, 1024, 4096};
     uint32_t max_chain = chains[level];
     if (max_chain > 256) max_chain = 256;
+    static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};     // good_match per level, deflate.c:142-168
+    const uint32_t good_match = goods[level];
 
     const size_t nseg = in_len ? (in_len + kSegBytes - 1) / kSegBytes : 1;
     std::vector<SegJob> jobs(nseg);
@@ -549,7 +552,8 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     ZR_HIP(hipMemcpyAsync(g_dyn.d_jobs, jobs.data(), nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
 
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain);
+    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain,
+                       good_match);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel,

@@ -118,7 +118,7 @@ struct LzPick {
 template <bool CHAIN, int HBITS, int NW = 4>   // NW = wavefronts per workgroup (batch = 64 * NW positions)
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
                                            LzShared<CHAIN, HBITS> *sh, int t, uint32_t max_chain = 0,
-                                           bool insert_only = false) {
+                                           bool insert_only = false, uint32_t good_match = 0xffffu) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
@@ -164,7 +164,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
             uint32_t c = old - 1u;
             uint32_t best = 3;                           // a match must reach WANT_MIN_MATCH to count
             uint32_t chain = max_chain;
-            bool done = false;
+            bool done = false, eased = false;
             while (!done && c != kLzNone) {
                 // walk up to kGather links first (LDS only), then fetch every candidate's probe words at once:
                 // one memory round trip per kGather candidates instead of one per candidate
@@ -204,6 +204,11 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                             best = l;
                             dist = p - cand[k];
                             if (l >= kLzChainProbe || l >= maxlen) done = true;     // nice_match reached
+                            if (!eased && best >= good_match) {     // "do not waste too much time if we already have a
+                                chain >>= 2;                        //  good match" (match_tpl.h:86-89), applied as soon
+                                eased = true;                       //  as the walk itself has found one
+                                if (chain == 0) done = true;
+                            }
                         }
                     }
                 }
