@@ -160,11 +160,55 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
             }
         }
     } else {
+        // 2a. the chain head alone (what the level-1 class does): a first estimate for every position
+        uint32_t best = 3;                               // a match must reach WANT_MIN_MATCH to count
+        uint32_t c = kLzNone;
         if (old && maxlen >= kLzMinMatch) {
-            uint32_t c = old - 1u;
-            uint32_t best = 3;                           // a match must reach WANT_MIN_MATCH to count
-            uint32_t chain = max_chain;
-            bool done = false, eased = false;
+            c = old - 1u;
+            if (c < p && p - c <= kLzMaxDist) {
+                const uint32_t l = lz_common_prefix(in, p, c, 0, kLzChainProbe, maxlen);
+                if (l >= kLzMinMatch) {
+                    best = l;
+                    dist = p - c;
+                }
+                const uint32_t d = sh->prev[c & 32767u];
+                c = (d == 0 || d > c) ? kLzNone : c - d;
+            } else {
+                c = kLzNone;
+            }
+        }
+        // 2b. which positions can the parse stop at?  Hop through this region with the estimates: token starts
+        //     (literals and matches) and the byte after a match start (lazy evaluation looks there).  Only those
+        //     lanes walk their chain -- the serial coder never searches inside a match it has already taken
+        //     (deflate_medium.c:187-239), and the probes of a walk are what this kernel's time is made of.
+        bool hot;
+        {
+            const uint32_t w0q = P + 64u * (uint32_t)wave;
+            const uint32_t limq = w0q >= n ? 0u : ((n - w0q) < 64u ? (n - w0q) : 64u);
+            const unsigned long long M0 = __ballot(best >= kLzMinMatch);
+            unsigned long long hm = 0;
+            uint32_t pos = 0;
+            while (pos < limq) {
+                const unsigned long long rest = M0 >> pos;
+                if (rest == 0) {
+                    hm |= lz_bits_below(limq) & ~lz_bits_below(pos);
+                    break;
+                }
+                const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
+                hm |= lz_bits_below(m + 2) & ~lz_bits_below(pos);      // [pos, m] and m + 1
+                pos = m + (uint32_t)__builtin_amdgcn_readlane((int)best, (int)m);
+            }
+            hot = (hm >> lane) & 1ull;
+        }
+        // 2c. the walk
+        if (hot && c != kLzNone && best < kLzChainProbe && best < maxlen) {
+            uint32_t chain = max_chain > 1 ? max_chain - 1 : 0;
+            bool done = chain == 0, eased = false;
+            if (best >= good_match) {
+                chain >>= 2;
+                eased = true;
+                done = chain == 0;
+            }
             while (!done && c != kLzNone) {
                 // walk up to kGather links first (LDS only), then fetch every candidate's probe words at once:
                 // one memory round trip per kGather candidates instead of one per candidate
@@ -213,8 +257,8 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                     }
                 }
             }
-            if (best >= kLzMinMatch) len = best;
         }
+        if (best >= kLzMinMatch) len = best;
     }
 
     // 3a. speculative parse of this wave's region [w0, w0 + lim)
