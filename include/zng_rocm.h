@@ -148,6 +148,12 @@ int zng_rocm_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstr
 int zng_rocm_longest_match_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint16_t *d_cur_match,
                                uint32_t *d_len_out, uint32_t *d_match_start_out, void *stream);
 
+/* slot `longest_match_slow` (match_tpl.h:26-280 with LONGEST_MATCH_SLOW; levels 7-8, update_hash = the
+ * multiplicative hash of insert_string.c:11-13): same interface as zng_rocm_longest_match_dev. */
+int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t nstreams,
+                                    const uint16_t *d_cur_match, uint32_t *d_len_out, uint32_t *d_match_start_out,
+                                    void *stream);
+
 /* ---- inflate-side copy primitive ------------------------------------------
  * slot `chunkmemset_safe` (chunkset_tpl.h:229-261) as a batch of INDEPENDENT copies inside one device
  * buffer: copy i writes out = d_base + d_out_off[i], reads from = d_base + d_from_off[i], with the

@@ -142,3 +142,108 @@ uint32_t oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match) {
     }
     return best_len;                                         /* :270 */
 }
+
+/* match_tpl.h:26-280 with LONGEST_MATCH_SLOW (arch/generic/compare256_c.c:54-58 -> longest_match_slow_c),
+ * byte-pair probes, s->update_hash = the multiplicative update_hash (levels 7-8; level 9 binds the rolling
+ * variant, insert_string_roll.c, which is out of scope -- SURVEY.md section 2 row 7). */
+uint32_t oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match) {
+    const uint32_t strstart = s->strstart;
+    const uint32_t wmask = s->w_mask;
+    const uint8_t *window = s->window;
+    const uint8_t *scan = window + strstart;
+    const uint8_t *mbase_start = window;
+    const oracle_pos *prev = s->prev;
+    const uint32_t lookahead = s->lookahead;
+    oracle_pos match_offset = 0;
+
+    uint32_t best_len = s->prev_length ? s->prev_length : ORACLE_STD_MIN_MATCH - 1;     /* :59 */
+    uint32_t offset = best_len - 1;                                                     /* :64 */
+    uint8_t end0 = scan[offset], end1 = scan[offset + 1];                               /* :81-84 */
+    uint32_t chain_length = s->max_chain_length;                                        /* :88-91 */
+    if (best_len >= s->good_match)
+        chain_length >>= 2;
+    const uint32_t nice_match = (uint32_t)s->nice_match;
+    const uint32_t max_dist = s->w_size - ORACLE_MIN_LOOKAHEAD;
+    oracle_pos limit = strstart > max_dist ? (oracle_pos)(strstart - max_dist) : 0;     /* :96 */
+    const oracle_pos limit_base = limit;                                                /* :98 */
+
+    if (best_len >= ORACLE_STD_MIN_MATCH) {                                             /* :99-125 */
+        uint32_t hash = oracle_update_hash(0, scan[1]);
+        hash = oracle_update_hash(hash, scan[2]);
+        for (uint32_t i = 3; i <= best_len; i++) {
+            hash = oracle_update_hash(hash, scan[i]);
+            oracle_pos pos = s->head[hash];
+            if (pos < cur_match) {
+                match_offset = (oracle_pos)(i - 2);
+                cur_match = pos;
+            }
+        }
+        limit = (oracle_pos)(limit_base + match_offset);
+        if (cur_match <= limit)
+            goto break_matching;
+        mbase_start -= match_offset;
+    }
+
+    for (;;) {
+        if (cur_match >= strstart)                                                      /* :131-132 */
+            break;
+        for (;;) {                                                                      /* :167-173 */
+            const uint8_t *cand = mbase_start + cur_match;
+            if (cand[offset] == end0 && cand[offset + 1] == end1 && cand[0] == scan[0] && cand[1] == scan[1])
+                break;
+            if (--chain_length && (cur_match = prev[cur_match & wmask]) > limit)        /* GOTO_NEXT_CHAIN */
+                continue;
+            return best_len;
+        }
+        uint32_t len = oracle_compare256(scan + 2, mbase_start + cur_match + 2) + 2;    /* :174 */
+        if (len > best_len) {
+            uint32_t match_start = (uint32_t)cur_match - match_offset;                  /* :178-179 */
+            s->match_start = match_start;
+            if (len > lookahead)
+                return lookahead;
+            best_len = len;
+            if (best_len >= nice_match)
+                return best_len;
+            offset = best_len - 1;
+            end0 = scan[offset];
+            end1 = scan[offset + 1];
+            if (len > ORACLE_STD_MIN_MATCH && match_start + len < strstart) {           /* :208-256 */
+                oracle_pos pos, next_pos;
+                cur_match = (oracle_pos)(cur_match - match_offset);
+                match_offset = 0;
+                next_pos = cur_match;
+                for (uint32_t i = 0; i <= len - ORACLE_STD_MIN_MATCH; i++) {
+                    pos = prev[(cur_match + i) & wmask];
+                    if (pos < next_pos) {
+                        if (pos <= limit_base + i)
+                            goto break_matching;
+                        next_pos = pos;
+                        match_offset = (oracle_pos)i;
+                    }
+                }
+                cur_match = next_pos;
+                const uint8_t *endstr = scan + len - (ORACLE_STD_MIN_MATCH + 1);
+                uint32_t hash = oracle_update_hash(0, endstr[0]);
+                hash = oracle_update_hash(hash, endstr[1]);
+                hash = oracle_update_hash(hash, endstr[2]);
+                pos = s->head[hash];
+                if (pos < cur_match) {
+                    match_offset = (oracle_pos)(len - (ORACLE_STD_MIN_MATCH + 1));
+                    if (pos <= limit_base + match_offset)
+                        goto break_matching;
+                    cur_match = pos;
+                }
+                limit = (oracle_pos)(limit_base + match_offset);
+                mbase_start = window - match_offset;
+                continue;
+            }
+        }
+        if (--chain_length && (cur_match = prev[cur_match & wmask]) > limit)            /* :268 */
+            continue;
+        return best_len;
+    }
+    return best_len;
+
+break_matching:                                                                         /* :272-278 */
+    return best_len < s->lookahead ? best_len : s->lookahead;
+}

@@ -79,6 +79,7 @@ uint32_t   oracle_update_hash(uint32_t h, uint32_t val);
 oracle_pos oracle_quick_insert_string(oracle_deflate_state *s, uint32_t str);
 void       oracle_insert_string(oracle_deflate_state *s, uint32_t str, uint32_t count);
 uint32_t   oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match);
+uint32_t   oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match);
 
 /* ---- inflate-side primitives (chunkset_tpl.h) -------------------------- */
 uint32_t   oracle_chunksize(void);

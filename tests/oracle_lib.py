@@ -74,6 +74,7 @@ def load():
     _sig(lib, "oracle_quick_insert_string", C.c_uint16, [C.POINTER(DeflateState), u32])
     _sig(lib, "oracle_insert_string", None, [C.POINTER(DeflateState), u32, u32])
     _sig(lib, "oracle_longest_match", u32, [C.POINTER(DeflateState), C.c_uint16])
+    _sig(lib, "oracle_longest_match_slow", u32, [C.POINTER(DeflateState), C.c_uint16])
     _sig(lib, "oracle_chunksize", u32, [])
     _sig(lib, "oracle_chunkmemset_safe", vp, [vp, vp, C.c_uint, C.c_uint])
     _LIB = lib

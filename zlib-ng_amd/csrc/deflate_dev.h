@@ -140,4 +140,82 @@ __device__ __forceinline__ uint32_t longest_match_wave(const MatchParams &s, uin
     return best_len;
 }
 
+// match_tpl.h:26-280 with LONGEST_MATCH_SLOW (the functable slot `longest_match_slow`, levels 7-8): besides the
+// chain walk it re-anchors the search on the most distant chain among the bytes of the current best match
+// (:94-125, :208-256), using head[] lookups of update_hash over single bytes exactly as the template does with the
+// multiplicative hash (insert_string.c:11-13).  Wave-uniform control flow, wave-wide compare256.
+__device__ __forceinline__ uint32_t longest_match_slow_wave(const MatchParams &s, const uint16_t *head,
+                                                            uint32_t cur_match, uint32_t *match_start_out, int lane) {
+    const uint8_t *window = s.window;
+    const uint8_t *scan = window + s.strstart;
+    uint32_t match_offset = 0;
+    uint32_t best_len = s.prev_length ? s.prev_length : kStdMinMatch - 1;
+    uint32_t offset = best_len - 1;
+    uint32_t chain_length = s.max_chain_length;
+    if (best_len >= s.good_match) chain_length >>= 2;
+    const uint32_t max_dist = s.w_size - kMinLookahead;
+    const uint32_t limit_base = s.strstart > max_dist ? (uint16_t)(s.strstart - max_dist) : 0;
+    uint32_t limit = limit_base;
+    const uint8_t sc0 = scan[0], sc1 = scan[1];
+    uint8_t end0 = scan[offset], end1 = scan[offset + 1];
+    auto give_up = [&]() { return best_len < s.lookahead ? best_len : s.lookahead; };      // break_matching :272-278
+
+    if (best_len >= kStdMinMatch) {
+        for (uint32_t i = 3; i <= best_len; ++i) {
+            const uint32_t pos = head[hash_calc(scan[i])];
+            if (pos < cur_match) {
+                match_offset = i - 2;
+                cur_match = pos;
+            }
+        }
+        limit = (uint16_t)(limit_base + match_offset);
+        if (cur_match <= limit) return give_up();
+    }
+    for (;;) {
+        if (cur_match >= s.strstart) break;
+        for (;;) {
+            const uint8_t *cand = window + cur_match - match_offset;
+            if (cand[offset] == end0 && cand[offset + 1] == end1 && cand[0] == sc0 && cand[1] == sc1) break;
+            if (--chain_length && (cur_match = s.prev[cur_match & s.w_mask]) > limit) continue;
+            return best_len;
+        }
+        const uint32_t len = compare256_wave(scan + 2, window + cur_match - match_offset + 2, lane) + 2;
+        if (len > best_len) {
+            const uint32_t match_start = cur_match - match_offset;
+            *match_start_out = match_start;
+            if (len > s.lookahead) return s.lookahead;
+            best_len = len;
+            if (best_len >= s.nice_match) return best_len;
+            offset = best_len - 1;
+            end0 = scan[offset];
+            end1 = scan[offset + 1];
+            if (len > kStdMinMatch && match_start + len < s.strstart) {
+                cur_match = (uint16_t)(cur_match - match_offset);
+                match_offset = 0;
+                uint32_t next_pos = cur_match;
+                for (uint32_t i = 0; i <= len - kStdMinMatch; ++i) {
+                    const uint32_t pos = s.prev[(cur_match + i) & s.w_mask];
+                    if (pos < next_pos) {
+                        if (pos <= limit_base + i) return give_up();
+                        next_pos = pos;
+                        match_offset = i;
+                    }
+                }
+                cur_match = next_pos;
+                const uint32_t pos = head[hash_calc(scan[len - (kStdMinMatch + 1) + 2])];
+                if (pos < cur_match) {
+                    match_offset = len - (kStdMinMatch + 1);
+                    if (pos <= limit_base + match_offset) return give_up();
+                    cur_match = pos;
+                }
+                limit = (uint16_t)(limit_base + match_offset);
+                continue;
+            }
+        }
+        if (--chain_length && (cur_match = s.prev[cur_match & s.w_mask]) > limit) continue;
+        return best_len;
+    }
+    return best_len;
+}
+
 }  // namespace zr

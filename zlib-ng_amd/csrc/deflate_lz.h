@@ -195,8 +195,12 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                     break;
                 }
                 const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
-                hm |= lz_bits_below(m + 2) & ~lz_bits_below(pos);      // [pos, m] and m + 1
-                pos = m + (uint32_t)__builtin_amdgcn_readlane((int)best, (int)m);
+                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)best, (int)m);
+                // [pos, m] and m + 1 always; the inside of a SHORT estimated match too (a deeper walk there often
+                // finds something better); only the inside of a long match is left alone
+                const uint32_t upto = L < 12u ? m + L : m + 2u;
+                hm |= lz_bits_below(upto < 64u ? upto : 64u) & ~lz_bits_below(pos);
+                pos = m + L;
             }
             hot = (hm >> lane) & 1ull;
         }

@@ -122,6 +122,34 @@ void longest_match_kernel(const zng_rocm_deflate_view *__restrict__ views, size_
     }
 }
 
+__global__ __launch_bounds__(256)
+void longest_match_slow_kernel(const zng_rocm_deflate_view *__restrict__ views, size_t nstreams,
+                               const uint16_t *__restrict__ cur_match, uint32_t *__restrict__ len_out,
+                               uint32_t *__restrict__ start_out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= nstreams) return;
+    const zng_rocm_deflate_view v = views[wave];
+    MatchParams mp;
+    mp.window = v.window;
+    mp.prev = v.prev;
+    mp.w_size = v.w_size;
+    mp.w_mask = v.w_mask;
+    mp.strstart = v.strstart;
+    mp.lookahead = v.lookahead;
+    mp.prev_length = v.prev_length;
+    mp.max_chain_length = v.max_chain_length;
+    mp.good_match = v.good_match;
+    mp.nice_match = (uint32_t)v.nice_match;
+    mp.level = v.level;
+    uint32_t ms = v.match_start;
+    const uint32_t len = longest_match_slow_wave(mp, v.head, cur_match[wave], &ms, lane);
+    if (lane == 0) {
+        len_out[wave] = len;
+        start_out[wave] = ms;
+    }
+}
+
 // ---- chunkmemset_safe ----------------------------------------------------------------
 // One wave per copy, len <= 258 in the inflate caller (any len accepted).  All source bytes of a
 // 64-byte-per-lane... rather: of a 256-byte round are loaded before any byte of that round is stored,
@@ -237,6 +265,18 @@ int zng_rocm_longest_match_dev(const zng_rocm_deflate_view *d_views, size_t nstr
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_cur_match || !d_len_out || !d_match_start_out) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(longest_match_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
+                       d_views, nstreams, d_cur_match, d_len_out, d_match_start_out);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t nstreams,
+                                    const uint16_t *d_cur_match, uint32_t *d_len_out, uint32_t *d_match_start_out,
+                                    void *stream) {
+    if (int rc = need_ctx()) return rc;
+    if (!nstreams) return ZNG_ROCM_OK;
+    if (!d_views || !d_cur_match || !d_len_out || !d_match_start_out) return ZNG_ROCM_EINVAL;
+    hipLaunchKernelGGL(longest_match_slow_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
                        d_views, nstreams, d_cur_match, d_len_out, d_match_start_out);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;

@@ -57,6 +57,8 @@ _PROTOS = {
     "zng_rocm_quick_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zng_rocm_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zng_rocm_longest_match_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zng_rocm_longest_match_slow_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]),
     "zng_rocm_chunkmemset_safe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]),
     "zng_rocm_chunksize": (C.c_uint32, []),
