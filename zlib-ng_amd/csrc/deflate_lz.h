@@ -241,7 +241,8 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                     ct[k] = cf[k] = 0;
                     if (k < nc) {
                         cf[k] = load_u32(in + cand[k]);
-                        ct[k] = can_tail ? load_u32(in + cand[k] + tail_off) : 0u;
+                        // no match yet (best == 3): the tail word IS the first word -- one gather, not two
+                        ct[k] = !can_tail ? 0u : (tail_off == 0 ? cf[k] : load_u32(in + cand[k] + tail_off));
                     }
                 }
 #pragma unroll
