@@ -245,19 +245,28 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
                         ct[k] = !can_tail ? 0u : (tail_off == 0 ? cf[k] : load_u32(in + cand[k] + tail_off));
                     }
                 }
+                // Survivors of the quick reject, as a per-lane bit mask.  Each lane then measures ITS OWN next
+                // survivor per pass: the passes a wave spends are the largest survivor count of any lane
+                // (typically 1-2), not kGather -- the full compares are where the walk's time went.
+                uint32_t pm = 0;
 #pragma unroll
-                for (int k = 0; k < kGather; ++k) {
-                    if (k < nc && !done && can_tail && cf[k] == val && ct[k] == want_tail) {
-                        const uint32_t l = lz_common_prefix(in, p, cand[k], 4, kLzChainProbe, maxlen);
-                        if (l > best) {
-                            best = l;
-                            dist = p - cand[k];
-                            if (l >= kLzChainProbe || l >= maxlen) done = true;     // nice_match reached
-                            if (!eased && best >= good_match) {     // "do not waste too much time if we already have a
-                                chain >>= 2;                        //  good match" (match_tpl.h:86-89), applied as soon
-                                eased = true;                       //  as the walk itself has found one
-                                if (chain == 0) done = true;
-                            }
+                for (int k = 0; k < kGather; ++k)
+                    if (k < nc && can_tail && cf[k] == val && ct[k] == want_tail) pm |= 1u << k;
+                while (pm && !done) {
+                    const int k = __ffs((int)pm) - 1;
+                    pm &= pm - 1u;
+                    uint32_t ck = cand[0];
+#pragma unroll
+                    for (int q = 1; q < kGather; ++q) ck = (q == k) ? cand[q] : ck;
+                    const uint32_t l = lz_common_prefix(in, p, ck, 4, kLzChainProbe, maxlen);
+                    if (l > best) {
+                        best = l;
+                        dist = p - ck;
+                        if (l >= kLzChainProbe || l >= maxlen) done = true;     // nice_match reached
+                        if (!eased && best >= good_match) {     // "do not waste too much time if we already have a
+                            chain >>= 2;                        //  good match" (match_tpl.h:86-89), applied as soon
+                            eased = true;                       //  as the walk itself has found one
+                            if (chain == 0) done = true;
                         }
                     }
                 }
