@@ -73,7 +73,7 @@ def pmc_traffic(kernel, nbytes):
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if name.endswith("_pmc_summary.json"):
+        if "_pmc_summary" in name and name.endswith(".json"):      # later files (sorted) win: newest build last
             try:
                 doc = json.load(open(os.path.join(pdir, name)))
             except ValueError:
