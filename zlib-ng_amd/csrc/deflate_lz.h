@@ -26,7 +26,7 @@
 namespace zr {
 
 constexpr uint32_t kLzMaxDist = 32768u - kMinLookahead;       // MAX_DIST(s)
-constexpr uint32_t kLzProbe = 32;                             // bytes compared per lane before the parse
+constexpr uint32_t kLzProbe = 36;                             // bytes compared per lane before the parse
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
 constexpr uint32_t kLzNone = 0xffffffffu;
 
@@ -151,12 +151,27 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     if constexpr (!CHAIN) {
         if (old) {
             const uint32_t c = old - 1u;
-            if (c < p && p - c <= kLzMaxDist) {
-                const uint32_t l = lz_common_prefix(in, p, c, 0, kLzProbe, maxlen);
-                if (l >= kLzMinMatch) {
-                    len = l;
-                    dist = p - c;
+            // Staged probe: the candidate side is a per-lane gather (every lane its own cache line), which is what
+            // this kernel is bound by -- so 4 bytes first (most candidates die there), then 16, then 16 more.
+            if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
+                uint32_t l = 4;
+#pragma unroll
+                for (int stage = 0; stage < 2 && l == 4u + 16u * (uint32_t)stage; ++stage) {
+                    if (l + 16 <= maxlen) {
+                        const u32x4_unaligned a = load_u128(in + p + l), b = load_u128(in + c + l);
+                        const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+                        uint32_t add = 16;
+#pragma unroll
+                        for (int j = 3; j >= 0; --j)
+                            if (x[j]) add = 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x[j]) - 1) >> 3);
+                        l += add;
+                    } else {
+                        while (l < maxlen && load_u8(in + p + l) == load_u8(in + c + l)) ++l;
+                        break;
+                    }
                 }
+                len = l;                                  // 36 = both stages matched: the parse extends it
+                dist = p - c;
             }
         }
     } else {
