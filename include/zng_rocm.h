@@ -205,7 +205,7 @@ int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8
  *   token (uint32): bit31 = 0 -> run of `tok` literals, taken in order from `literals`
  *                   bit31 = 1 -> match: length = ((tok >> 16) & 0xff) + 3, distance = (tok & 0xffff) + 1
  *   segs: (nsegs + 1) triples {first token, first output byte, first literal}; every segment but
- *         the last holds >= 128 KiB (and < 128 KiB + 258) of output, so a match never reaches
+ *         the last holds >= 32 KiB (and < 32 KiB + 258) of output, so a match never reaches
  *         further back than the previous segment.
  * status / msg follow zlib: 1 = Z_STREAM_END, -3 = Z_DATA_ERROR with the reference's strm->msg text
  * (inflate.c:735-917, inffast_tpl.h:189-226), -5 = input ended early, -4 = out of memory.  On an
@@ -223,9 +223,10 @@ typedef struct zng_rocm_inflate_tokens {
 int  zng_rocm_inflate_tokens_decode(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *out);
 void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
 /* Device stage on device-resident token arrays.  d_symbols: workspace of out_len uint16_t;
- * d_out: out_len bytes.  Three launches: per-segment resolution into 16-bit symbols (a symbol
- * >= 256 names a byte of the previous segment's last 32 KiB), the sequential context chain, and the
- * final translate. */
+ * d_out: out_len bytes.  Up to four launches: per-segment resolution into 16-bit symbols (a symbol
+ * >= 256 names a byte of the previous segment's last 32 KiB), the context chain over those 32 KiB
+ * tails in two levels, and the final translate.  `segs` must keep the >= 32 KiB-per-segment rule
+ * above (zng_rocm_inflate_tokens_decode does). */
 int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
                                   size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
                                   uint8_t *d_out, uint64_t out_len, void *stream);

@@ -62,6 +62,26 @@ def test_corpus_levels(inf):
     assert inf.resolve_dev(inf.decode_tokens(comp)).cpu().numpy().tobytes() == cases["mix"]
 
 
+def test_context_chain_across_groups(inf):
+    """Worst case for the two-level context chain: after the first 32 KiB every byte is a distance-32768 (or
+    distance-1 / distance-7) reference, so every symbol of every segment tail stays a reference until the
+    chain has walked all the way back to segment 0, across several groups of 32 segments."""
+    rng = np.random.default_rng(5)
+    block = rng.integers(0, 256, size=32768, dtype=np.uint8).tobytes()
+    cases = {
+        "far": block * 420,                                       # 13 MiB, > 100 segments, 4 groups
+        "near": block + b"\x07" * (9 << 20) + b"abcdefg" * 600000,
+        "ragged": (block + b"tail") * 300 + block[:12345],
+    }
+    for name, data in cases.items():
+        for level in (1, 6):
+            comp = _raw_deflate(data, level)
+            dec = inf.decode_tokens(comp)
+            assert dec.status == 1 and dec.out_len == len(data) and dec.nsegs > 64, name
+            got = inf.resolve_dev(dec).cpu().numpy().tobytes()
+            assert got == data, (name, level)
+
+
 def test_one_shot_inflate_raw_and_errors(inf):
     torch = torch_mod()
     data = synth.silesia_like(2 << 20, seed=11, seg_bytes=256 << 10).tobytes()

@@ -81,13 +81,13 @@ def test_streams_from_python_zlib(level):
             assert dec.status == 1 and dec.in_used == len(comp), (name, level)
             assert dec.out_len == len(data)
             assert replay(dec) == data, (name, level)
-            # segment table: monotone, >= 128 KiB each but the last, terminal triple closes the arrays
+            # segment table: monotone, >= 32 KiB each but the last, terminal triple closes the arrays
             segs = dec.segs.reshape(-1, 3)
             assert segs.shape[0] == dec.nsegs + 1
             assert tuple(segs[0]) == (0, 0, 0)
             assert tuple(segs[-1]) == (dec.tokens.size, len(data), dec.literals.size)
             sizes = np.diff(segs[:, 1].astype(np.int64))
-            assert (sizes[:-1] >= 128 * 1024).all() and (sizes <= 128 * 1024 + 258).all()
+            assert (sizes[:-1] >= 32 * 1024).all() and (sizes <= 32 * 1024 + 258).all()
 
 
 def test_truncated_and_corrupt_inputs_match_oracle():

@@ -156,7 +156,7 @@ struct Out {
     bool oom;
 };
 
-constexpr uint64_t kSegTarget = 128u << 10;    // a segment closes once it holds >= 128 KiB of output
+constexpr uint64_t kSegTarget = 32u << 10;     // a segment closes once it holds >= 32 KiB of output
 constexpr uint32_t kMaxRun = 0x7fffffffu;
 
 inline void grow(void **p, size_t *cap, size_t need, size_t elt, bool *oom) {

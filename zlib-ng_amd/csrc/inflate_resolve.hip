@@ -3,13 +3,14 @@
 // stores, :228-279 match copies via CHUNKCOPY / CHUNKMEMSET, chunkset_tpl.h:24-227) re-designed for a
 // machine that wants thousands of independent copy streams:
 //
-//   K1 segments  one wavefront per >=128 KiB output segment walks its tokens in order and writes 16-bit
+//   K1 segments  one wavefront per >=32 KiB output segment  walks its tokens in order and writes 16-bit
 //                SYMBOLS: a literal byte, or 256 + k meaning "byte k of the 32 KiB that precede this
 //                segment".  Copies inside the segment move symbols, so unresolved references
 //                propagate by themselves; no segment waits for another.  The wave's last 4096 symbols
 //                live in an LDS ring (the device form of inflate's sliding window, inflate.c:325-378).
-//   K2 context   one workgroup walks the segments in order and finalises only the last 32 KiB of each
-//                (the only bytes a later segment can name) -- 32 KiB per step instead of the whole stream.
+//   K2 context   only the last 32 KiB of a segment can be named by the next one.  Those tails are resolved
+//                against each other in two levels (groups of 32 in parallel, then one walk over the groups):
+//                32 + nsegs / 32 dependent steps of 32 KiB instead of nsegs.
 //   K3 translate all symbols -> bytes, fully parallel: 2N read + N written, HBM-bound.
 //
 // Algorithmic bytes: C + U per stream; the symbol detour adds 4U of HBM traffic.
@@ -121,52 +122,78 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
     flush(op);
 }
 
-// K2.  One workgroup; segment s (s >= 0) gets the last 32 KiB of its output finalised, in order.  Each lane owns
-// 32 symbols of the 32 KiB; all its loads are issued before any is used, so one step costs a few memory round
-// trips (symbol loads, context gathers, stores) instead of 32 dependent ones.
-__global__ __launch_bounds__(1024)
-void inflate_context_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
-                            uint8_t *__restrict__ out) {
+// K2.  Only the last 32 KiB of a segment (its TAIL) can be named by the next segment, and the tail of segment
+// s names the tail of segment s-1 and nothing else (every segment but the last holds >= 32 KiB).  A straight
+// walk over the tails is nsegs dependent steps; two levels make it kGroup + nsegs / kGroup:
+//   pass A  one workgroup per group of kGroup segments rewrites, in order, each tail of its group against the
+//           tail before it.  Afterwards a tail's remaining references (>= 256) all name the tail that
+//           precedes the GROUP (its base), whichever segment of the group they sit in.
+//   pass B  one workgroup walks the groups in order and resolves the last tail of each against its base;
+//           those are then plain bytes.
+// K3 finishes the rest: a tail symbol needs one lookup in its group's base, any other symbol one lookup in the
+// previous segment's tail plus, when that is still a reference, one in that tail's base.
+// Each lane owns 32 symbols of the 32 KiB; all its loads are issued before any is used, so one step costs a
+// few memory round trips instead of 32 dependent ones.
+constexpr size_t kGroup = 64;
+
+__device__ __forceinline__ void tail_step(uint16_t *__restrict__ sym, long long cur_end, long long prev_end) {
     constexpr int PER = (int)(kCtx / 1024);            // 32
-    for (size_t s = 0; s + 1 < nsegs; ++s) {
-        const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
-        long long lo = o1 - kCtx;
-        if (lo < o0) lo = o0;
-        const long long ctx_base = o0 - kCtx;
-        uint16_t v[PER];
+    uint16_t v[PER];
+    uint16_t *cur = sym + (cur_end - kCtx);
+    const uint16_t *prev = sym + (prev_end - kCtx);
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const long long i = lo + threadIdx.x + 1024LL * k;
-            v[k] = i < o1 ? sym[i] : (uint16_t)0;
-        }
+    for (int k = 0; k < PER; ++k) v[k] = cur[threadIdx.x + 1024 * k];
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (v[k] >= 256) v[k] = out[ctx_base + (v[k] - 256)];
+    for (int k = 0; k < PER; ++k)
+        if (v[k] >= 256) v[k] = prev[v[k] - 256];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const long long i = lo + threadIdx.x + 1024LL * k;
-            if (i < o1) out[i] = (uint8_t)v[k];
-        }
-        __threadfence_block();
-        __syncthreads();
+    for (int k = 0; k < PER; ++k) cur[threadIdx.x + 1024 * k] = v[k];
+    __threadfence_block();
+    __syncthreads();
+}
+
+// grid.x = group.  Tails exist for segments 0 .. nsegs-2.
+__global__ __launch_bounds__(1024)
+void inflate_context_group_kernel(const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
+    const size_t first = (size_t)blockIdx.x * kGroup;
+    size_t last = first + kGroup;
+    if (last > nsegs - 1) last = nsegs - 1;
+    for (size_t s = first + 1; s < last; ++s)
+        tail_step(sym, (long long)segs[3 * s + 4], (long long)segs[3 * s + 1]);
+}
+
+// one workgroup; group g >= 1: its last tail against the last tail of group g-1
+__global__ __launch_bounds__(1024)
+void inflate_context_chain_kernel(const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
+    for (size_t first = kGroup; first < nsegs - 1; first += kGroup) {
+        size_t last = first + kGroup;
+        if (last > nsegs - 1) last = nsegs - 1;
+        tail_step(sym, (long long)segs[3 * (last - 1) + 4], (long long)segs[3 * first + 1]);
     }
 }
 
-// grid.x = segment; bytes the context kernel already wrote are left alone
+// K3.  grid.x = segment
 __global__ __launch_bounds__(1024)
 void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
                               uint8_t *__restrict__ out) {
     const size_t s = blockIdx.x;
     const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
-    long long hi = o1;
-    if (s + 1 < nsegs) {
-        hi = o1 - kCtx;
-        if (hi < o0) hi = o0;
-    }
-    const long long ctx_base = o0 - kCtx;
-    for (long long i = o0 + threadIdx.x; i < hi; i += blockDim.x) {
+    const long long tail = s + 1 < nsegs ? o1 - kCtx : o1;          // first symbol pass A/B rewrote
+    const uint16_t *prev = sym + (o0 - kCtx);                       // tail of segment s-1
+    const size_t gs = (s / kGroup) * kGroup;                        // base of this segment's group ...
+    const uint16_t *base_own = sym + ((long long)segs[3 * gs + 1] - kCtx);
+    const size_t gp = s ? ((s - 1) / kGroup) * kGroup : 0;          // ... and of the previous segment's
+    const uint16_t *base_prev = sym + ((long long)segs[3 * gp + 1] - kCtx);
+    for (long long i = o0 + threadIdx.x; i < o1; i += blockDim.x) {
         uint16_t v = sym[i];
-        if (v >= 256) v = out[ctx_base + (v - 256)];
+        if (v >= 256) {
+            if (i >= tail) {
+                v = base_own[v - 256];
+            } else {
+                v = prev[v - 256];
+                if (v >= 256) v = base_prev[v - 256];
+            }
+        }
         out[i] = (uint8_t)v;
     }
 }
@@ -192,8 +219,13 @@ int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const
                        d_literals, nliterals, d_segs, nsegs, d_symbols);
     ZR_HIP(hipGetLastError());
     if (nsegs > 1) {
-        hipLaunchKernelGGL(inflate_context_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, d_symbols, d_out);
+        const unsigned ngroups = (unsigned)((nsegs - 1 + kGroup - 1) / kGroup);
+        hipLaunchKernelGGL(inflate_context_group_kernel, dim3(ngroups), dim3(1024), 0, st, d_segs, nsegs, d_symbols);
         ZR_HIP(hipGetLastError());
+        if (ngroups > 1) {
+            hipLaunchKernelGGL(inflate_context_chain_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, d_symbols);
+            ZR_HIP(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, d_symbols,
                        d_out);
