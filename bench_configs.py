@@ -107,6 +107,50 @@ def main():
         report["cfg2"] = rows
         del big, dst
 
+    # ---- chunkset: the inflate copy primitive as a batch of independent copies (north_star's third kernel) ----
+    # Outputs tile one region back to back (as inflate's output does); sources are drawn from another region.
+    # Algorithmic bytes per copy: len read + len written + 24 of descriptors.
+    if want("chunkset"):
+        rows = []
+        rng = np.random.default_rng(0xC0B1)
+        src_bytes = (64 if args.quick else 256) << 20
+        base = torch.randint(0, 256, (2 * src_bytes + 4096,), dtype=torch.uint8, device="cuda")
+        for name, lens in (
+                ("len 258 (the inflate caller's maximum)", np.full(src_bytes // 258, 258, dtype=np.uint32)),
+                ("len 256", np.full(src_bytes // 256, 256, dtype=np.uint32)),
+                ("len uniform 3..258", rng.integers(3, 259, size=src_bytes // 131, dtype=np.uint32)),
+                ("len 4096", np.full(src_bytes // 4096, 4096, dtype=np.uint32))):
+            ncopy = lens.size
+            out_off = src_bytes + np.concatenate(([0], np.cumsum(lens[:-1], dtype=np.uint64))).astype(np.uint64)
+            from_off = rng.integers(0, src_bytes - 4096, size=ncopy, dtype=np.uint64)
+            d_out = torch.from_numpy(out_off.view(np.int64)).cuda()
+            d_from = torch.from_numpy(from_off.view(np.int64)).cuda()
+            d_len = torch.from_numpy(lens.view(np.int32)).cuda()
+            fn = lambda: zr.rocm.chunkmemset_safe_dev(base, d_out, d_from, d_len, d_len)
+            for _ in range(200):                                   # clocks settle
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(50):
+                fn()
+            b.record()
+            b.synchronize()
+            ms = a.elapsed_time(b) / 50
+            moved = int(lens.sum())
+            alg = 2 * moved + 24 * ncopy
+            # parity on a sample of the copies
+            host = base.cpu().numpy()
+            ok = all(bytes(host[int(out_off[k]):int(out_off[k]) + int(lens[k])])
+                     == bytes(host[int(from_off[k]):int(from_off[k]) + int(lens[k])])
+                     for k in rng.integers(0, ncopy, size=200))
+            rows.append({"case": name, "copies": ncopy, "bytes_moved_MiB": round(moved / 2**20, 1), "kernel_ms": round(ms, 4),
+                         "copied_GBps": round(moved / 1e9 / (ms / 1e3), 1),
+                         "algorithmic_GBps": round(alg / 1e9 / (ms / 1e3), 1),
+                         "frac_of_8TBps": round(alg / 1e9 / (ms / 1e3) / 8000, 3), "sample_bit_exact": bool(ok)})
+        report["chunkset"] = rows
+        del base
+
     # ---- cfg3: raw inflate of a level-6 stream ----------------------------------------------------------
     if want("cfg3"):
         n = (32 if args.quick else 256) << 20

@@ -187,3 +187,32 @@ def test_baseline_sizes(zr, oracle, mib):
             assert got[0] == oracle.oracle_adler32(1, host.ctypes.data, n)
             assert got[1] == oracle.oracle_crc32_braid(0, host.ctypes.data, n)
             del host
+
+
+def test_slots_from_concurrent_host_threads(zr, oracle):
+    """The reference's slots are called from any number of application threads at once (its
+    test_deflate_concurrency.cc drives two streams from two threads).  Each host thread gets its own HIP
+    stream and workspace inside the library; ctypes drops the GIL for the call, so these really overlap."""
+    import threading
+    bufs = [seeded_bytes((1 << 20) * (k + 1) + 17 * k, seed=100 + k) for k in range(4)]
+    want = [(oracle.oracle_adler32(1, b.ctypes.data, b.size), oracle.oracle_crc32(0, b.ctypes.data, b.size))
+            for b in bufs]
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(12):
+                a = zr.adler32_z(1, bufs[k])
+                c = zr.crc32_z(0, bufs[k])
+                if (a, c) != want[k]:
+                    errors.append((k, a, c, want[k]))
+                    return
+        except Exception as e:      # noqa: BLE001 - surfaced through the assert below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -173,7 +173,7 @@ def test_chunkmemset_safe(zr, oracle):
     cases = []
     slot = 34000
     dists = list(range(1, 65)) + [255, 256, 257, 32768]
-    lens = list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 258, 600]
+    lens = list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 258, 271, 272, 273, 600, 1000, 1200]
     for d in dists:
         for ln in lens:
             cases.append((d, ln, ln + int(rng.integers(0, 40))))

@@ -151,42 +151,71 @@ void longest_match_slow_kernel(const zng_rocm_deflate_view *__restrict__ views, 
 }
 
 // ---- chunkmemset_safe ----------------------------------------------------------------
-// One wave per copy, len <= 258 in the inflate caller (any len accepted).  All source bytes of a
-// 64-byte-per-lane... rather: of a 256-byte round are loaded before any byte of that round is stored,
-// and rounds go in ascending order, which reproduces the forward byte-serial semantics:
-//   from < out, dist < len : byte i comes from from[i % dist]  (only original bytes are read)
-//   otherwise              : byte i comes from from[i]; for `from` ahead of `out` ascending rounds with
+// Sixteen lanes per copy (four copies per wave), sixteen bytes per lane: a round moves 256 bytes of a copy
+// with one unaligned dwordx4 load and one dwordx4 store per lane, so the <= 258-byte copies of the inflate
+// caller are a single round plus a two-byte tail.  Any len is accepted; rounds go in ascending order and every
+// load of a round lands before any store of that round is issued, which reproduces the forward byte-serial
+// semantics of the reference:
+//   from < out, dist < len : byte i comes from from[i % dist]  (only original bytes are ever read)
+//   otherwise              : byte i comes from from[i]; for `from` ahead of `out`, ascending rounds with
 //                            load-before-store are exactly memmove.
+// The ragged end of a copy (len % 16 bytes) goes one byte per lane in the copy's last round, so a 258-byte copy
+// is one dwordx4 and one byte access each way per lane; a lane whose sixteen bytes are not one contiguous run of
+// the source (the pattern wraps inside them) gathers them bytewise.  Nothing outside [out, out+len) is written
+// and nothing outside [from, from+len) is read.
+// Measured and rejected: 2 or 4 copies in flight per 16-lane group (slower: 0.59 -> 0.53 / 0.45 of peak at len
+// 256), and a byte head that aligns the dwordx4 stores (no gain; the extra byte access costs more).
+typedef uint32_t u32x4_plain __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256)
 void chunkmemset_kernel(uint8_t *__restrict__ base, const uint64_t *__restrict__ out_off,
                         const uint64_t *__restrict__ from_off, const uint32_t *__restrict__ len_in,
                         const uint32_t *__restrict__ left_in, size_t ncopies) {
-    const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wave >= ncopies) return;
-    uint8_t *out = base + out_off[wave];
-    const uint8_t *from = base + from_off[wave];
-    uint32_t len = len_in[wave];
-    const uint32_t left = left_in[wave];
-    if (len > left) len = left;                                     // chunkset_tpl.h:236
+    const uint32_t l = threadIdx.x & 15u;
+    const size_t copy = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    uint8_t *out = base;
+    const uint8_t *from = base;
+    uint32_t len = 0;
+    if (copy < ncopies) {
+        out = base + out_off[copy];
+        from = base + from_off[copy];
+        len = len_in[copy];
+        const uint32_t left = left_in[copy];
+        if (len > left) len = left;                                 // chunkset_tpl.h:236
+    }
     const bool behind = from < out;
     const uint64_t dist = behind ? (uint64_t)(out - from) : (uint64_t)(from - out);
     const bool pattern = behind && dist < len;
-    for (uint32_t round = 0; round < len; round += 256) {
-        uint8_t b[4];
+    const uint32_t period = pattern ? (uint32_t)dist : 0xffffffffu;   // source bytes repeat with this period
+    uint32_t round = 0;
+    bool live = len != 0u;
+    while (__ballot(live) != 0ull) {
+        // this round: `full` sixteen-byte lanes, then `ntail` < 16 single bytes (only in a copy's last round)
+        const uint32_t remaining = live ? len - round : 0u;
+        const uint32_t span = remaining < 272u ? remaining : 256u;
+        const uint32_t full = span >> 4, ntail = span & 15u;
+        const uint32_t i = round + 16u * l;
+        u32x4_plain v = {0u, 0u, 0u, 0u};
+        if (l < full) {
+            uint32_t r = pattern ? i % period : i;
+            if (period - r >= 16u) {
+                v = load_u128(from + r);
+            } else {                                                 // the pattern wraps inside these 16 bytes
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = round + (uint32_t)k * 64u + (uint32_t)lane;
-            b[k] = 0;
-            if (i < len) b[k] = pattern ? from[i % dist] : from[i];
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    v[j >> 2] |= (uint32_t)load_u8(from + r) << (8u * (j & 3u));
+                    r = r + 1u == period ? 0u : r + 1u;
+                }
+            }
         }
+        const uint32_t p = round + 16u * full + l;
+        uint8_t tb = 0;
+        if (l < ntail) tb = load_u8(from + (pattern ? p % period : p));
         __builtin_amdgcn_s_waitcnt(0);                               // every load of the round has landed
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = round + (uint32_t)k * 64u + (uint32_t)lane;
-            if (i < len) out[i] = b[k];
-        }
-        __builtin_amdgcn_s_waitcnt(0);
+        if (l < full) *(ZR_GLOBAL u32x4_unaligned *)(out + i) = v;
+        if (l < ntail) *(ZR_GLOBAL uint8_t *)(out + p) = tb;
+        round += span;
+        live = live && round < len;
     }
 }
 
@@ -287,7 +316,7 @@ int zng_rocm_chunkmemset_safe_dev(uint8_t *d_base, const uint64_t *d_out_off, co
     if (int rc = need_ctx()) return rc;
     if (!ncopies) return ZNG_ROCM_OK;
     if (!d_base || !d_out_off || !d_from_off || !d_len || !d_left) return ZNG_ROCM_EINVAL;
-    hipLaunchKernelGGL(chunkmemset_kernel, dim3(waves_to_blocks(ncopies)), dim3(256), 0, (hipStream_t)stream, d_base,
+    hipLaunchKernelGGL(chunkmemset_kernel, dim3((unsigned)((ncopies + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_base,
                        d_out_off, d_from_off, d_len, d_left, ncopies);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
