@@ -142,14 +142,24 @@ int zng_rocm_quick_insert_string_dev(const zng_rocm_deflate_view *d_views, size_
  * in order. */
 int zng_rocm_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
                                const uint32_t *d_count, void *stream);
+/* The rolling-hash instantiation of the same three (insert_string_roll.c:10-24: HASH_SLIDE 5, one byte read
+ * at str + 2, mask 32767), which lm_init binds for level 9 (max_chain_length > 1024, deflate.c:1223-1234).
+ * The running key s->ins_h (deflate.h:196) is per stream: d_ins_h[i] is read and updated.
+ * update_hash_roll: d_hash[i] = ((d_h[i] << 5) ^ (uint8_t)d_val[i]) & 32767. */
+int zng_rocm_update_hash_roll_dev(const uint32_t *d_h, const uint32_t *d_val, size_t n, uint32_t *d_hash, void *stream);
+int zng_rocm_quick_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                                          uint32_t *d_ins_h, uint16_t *d_head_out, void *stream);
+int zng_rocm_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                                    const uint32_t *d_count, uint32_t *d_ins_h, void *stream);
 /* slot `longest_match` (match_tpl.h:26-280, non-SLOW): for stream i walks the chain from d_cur_match[i];
  * d_len_out[i] = returned length, d_match_start_out[i] = s->match_start afterwards (unchanged if no
  * longer match was found). */
 int zng_rocm_longest_match_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint16_t *d_cur_match,
                                uint32_t *d_len_out, uint32_t *d_match_start_out, void *stream);
 
-/* slot `longest_match_slow` (match_tpl.h:26-280 with LONGEST_MATCH_SLOW; levels 7-8, update_hash = the
- * multiplicative hash of insert_string.c:11-13): same interface as zng_rocm_longest_match_dev. */
+/* slot `longest_match_slow` (match_tpl.h:26-280 with LONGEST_MATCH_SLOW; levels 7-9).  s->update_hash is the
+ * multiplicative hash of insert_string.c:11-13 for levels 7-8 and the rolling one for level 9, chosen as
+ * lm_init does by max_chain_length > 1024.  Same interface as zng_rocm_longest_match_dev. */
 int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t nstreams,
                                     const uint16_t *d_cur_match, uint32_t *d_len_out, uint32_t *d_match_start_out,
                                     void *stream);

@@ -73,6 +73,37 @@ void oracle_insert_string(oracle_deflate_state *s, uint32_t str, uint32_t count)
     }
 }
 
+/* insert_string_roll.c:10-24 instantiating insert_string_tpl.h: HASH_SLIDE 5, one byte read at
+ * str + STD_MIN_MATCH-1, mask 32767, and the key lives in s->ins_h between calls. */
+uint32_t oracle_update_hash_roll(uint32_t h, uint32_t val) {
+    return ((h << 5) ^ (uint8_t)val) & 32767u;
+}
+
+oracle_pos oracle_quick_insert_string_roll(oracle_deflate_state *s, uint32_t str) {
+    s->ins_h = oracle_update_hash_roll(s->ins_h, s->window[str + ORACLE_STD_MIN_MATCH - 1]);
+    const uint32_t slot = s->ins_h;
+    oracle_pos head = s->head[slot];
+    if (head != str) {
+        s->prev[str & s->w_mask] = head;
+        s->head[slot] = (oracle_pos)str;
+    }
+    return head;
+}
+
+void oracle_insert_string_roll(oracle_deflate_state *s, uint32_t str, uint32_t count) {
+    const uint8_t *p = s->window + str + ORACLE_STD_MIN_MATCH - 1;
+    oracle_pos idx = (oracle_pos)str;
+    for (uint32_t i = 0; i < count; i++, idx++, p++) {
+        s->ins_h = oracle_update_hash_roll(s->ins_h, *p);
+        const uint32_t slot = s->ins_h;
+        oracle_pos head = s->head[slot];
+        if (head != idx) {
+            s->prev[idx & s->w_mask] = head;
+            s->head[slot] = idx;
+        }
+    }
+}
+
 /* match_tpl.h:26-280, non-SLOW, byte-pair probes (OPTIMAL_CMP < 32). */
 uint32_t oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match) {
     const uint32_t strstart = s->strstart;
@@ -144,9 +175,11 @@ uint32_t oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match) {
 }
 
 /* match_tpl.h:26-280 with LONGEST_MATCH_SLOW (arch/generic/compare256_c.c:54-58 -> longest_match_slow_c),
- * byte-pair probes, s->update_hash = the multiplicative update_hash (levels 7-8; level 9 binds the rolling
- * variant, insert_string_roll.c, which is out of scope -- SURVEY.md section 2 row 7). */
+ * byte-pair probes.  s->update_hash is the multiplicative update_hash for levels 7-8 and the rolling one for
+ * level 9; lm_init binds it by max_chain_length > 1024 (deflate.c:1223-1234), and so does this. */
 uint32_t oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match) {
+    uint32_t (*const update_hash)(uint32_t, uint32_t) =
+        s->max_chain_length > 1024 ? oracle_update_hash_roll : oracle_update_hash;
     const uint32_t strstart = s->strstart;
     const uint32_t wmask = s->w_mask;
     const uint8_t *window = s->window;
@@ -168,10 +201,10 @@ uint32_t oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match
     const oracle_pos limit_base = limit;                                                /* :98 */
 
     if (best_len >= ORACLE_STD_MIN_MATCH) {                                             /* :99-125 */
-        uint32_t hash = oracle_update_hash(0, scan[1]);
-        hash = oracle_update_hash(hash, scan[2]);
+        uint32_t hash = update_hash(0, scan[1]);
+        hash = update_hash(hash, scan[2]);
         for (uint32_t i = 3; i <= best_len; i++) {
-            hash = oracle_update_hash(hash, scan[i]);
+            hash = update_hash(hash, scan[i]);
             oracle_pos pos = s->head[hash];
             if (pos < cur_match) {
                 match_offset = (oracle_pos)(i - 2);
@@ -223,9 +256,9 @@ uint32_t oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match
                 }
                 cur_match = next_pos;
                 const uint8_t *endstr = scan + len - (ORACLE_STD_MIN_MATCH + 1);
-                uint32_t hash = oracle_update_hash(0, endstr[0]);
-                hash = oracle_update_hash(hash, endstr[1]);
-                hash = oracle_update_hash(hash, endstr[2]);
+                uint32_t hash = update_hash(0, endstr[0]);
+                hash = update_hash(hash, endstr[1]);
+                hash = update_hash(hash, endstr[2]);
                 pos = s->head[hash];
                 if (pos < cur_match) {
                     match_offset = (oracle_pos)(len - (ORACLE_STD_MIN_MATCH + 1));

@@ -71,6 +71,7 @@ typedef struct oracle_deflate_state {
     uint32_t    good_match;
     int32_t     nice_match;
     int32_t     level;
+    uint32_t    ins_h;          /* running key of the rolling hash (deflate.h:196; level 9 only) */
 } oracle_deflate_state;
 
 void       oracle_slide_hash(oracle_deflate_state *s);
@@ -78,6 +79,10 @@ uint32_t   oracle_compare256(const uint8_t *src0, const uint8_t *src1);
 uint32_t   oracle_update_hash(uint32_t h, uint32_t val);
 oracle_pos oracle_quick_insert_string(oracle_deflate_state *s, uint32_t str);
 void       oracle_insert_string(oracle_deflate_state *s, uint32_t str, uint32_t count);
+/* insert_string_roll.c (level 9: bound when max_chain_length > 1024, deflate.c:1223-1234) */
+uint32_t   oracle_update_hash_roll(uint32_t h, uint32_t val);
+oracle_pos oracle_quick_insert_string_roll(oracle_deflate_state *s, uint32_t str);
+void       oracle_insert_string_roll(oracle_deflate_state *s, uint32_t str, uint32_t count);
 uint32_t   oracle_longest_match(oracle_deflate_state *s, oracle_pos cur_match);
 uint32_t   oracle_longest_match_slow(oracle_deflate_state *s, oracle_pos cur_match);
 

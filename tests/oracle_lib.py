@@ -21,7 +21,7 @@ class DeflateState(C.Structure):
         ("window", C.c_void_p), ("prev", C.c_void_p), ("head", C.c_void_p),
         ("strstart", C.c_uint32), ("match_start", C.c_uint32), ("prev_length", C.c_uint32),
         ("max_chain_length", C.c_uint32), ("good_match", C.c_uint32),
-        ("nice_match", C.c_int32), ("level", C.c_int32),
+        ("nice_match", C.c_int32), ("level", C.c_int32), ("ins_h", C.c_uint32),
     ]
 
 
@@ -73,6 +73,9 @@ def load():
     _sig(lib, "oracle_update_hash", u32, [u32, u32])
     _sig(lib, "oracle_quick_insert_string", C.c_uint16, [C.POINTER(DeflateState), u32])
     _sig(lib, "oracle_insert_string", None, [C.POINTER(DeflateState), u32, u32])
+    _sig(lib, "oracle_update_hash_roll", u32, [u32, u32])
+    _sig(lib, "oracle_quick_insert_string_roll", C.c_uint16, [C.POINTER(DeflateState), u32])
+    _sig(lib, "oracle_insert_string_roll", None, [C.POINTER(DeflateState), u32, u32])
     _sig(lib, "oracle_longest_match", u32, [C.POINTER(DeflateState), C.c_uint16])
     _sig(lib, "oracle_longest_match_slow", u32, [C.POINTER(DeflateState), C.c_uint16])
     _sig(lib, "oracle_chunksize", u32, [])

@@ -127,6 +127,50 @@ def test_insert_string_and_quick_insert(zr, oracle):
             assert (d.head_np() == hs.head).all() and (d.prev_np() == hs.prev).all()
 
 
+def test_rolling_hash_insert_family(zr, oracle):
+    """insert_string_roll.c (level 9): update_hash_roll, insert_string_roll, quick_insert_string_roll with the
+    running key s->ins_h carried per stream, bit-exact against the oracle (head, prev and the key)."""
+    torch = torch_mod()
+    rng = np.random.default_rng(21)
+    hv = rng.integers(0, 2**32, size=4000, dtype=np.uint64).astype(np.uint32)
+    vv = rng.integers(0, 2**32, size=4000, dtype=np.uint64).astype(np.uint32)
+    out = torch.zeros(hv.size, dtype=torch.int32, device="cuda")
+    zr.rocm.update_hash_roll_dev(torch.from_numpy(hv.view(np.int32)).cuda(), torch.from_numpy(vv.view(np.int32)).cuda(), out)
+    got = out.cpu().numpy().view(np.uint32)
+    for i in range(0, hv.size, 5):
+        assert got[i] == oracle.oracle_update_hash_roll(int(hv[i]), int(vv[i]))
+
+    plans = [(0, 1), (1, 1), (2, 1), (3, 61), (64, 64), (128, 65), (193, 1000), (1193, 0), (1193, 30000), (31193, 2)]
+    states = [HostState(texty(60000, s, alphabet=a, words=w)) for s, a, w in ((3, 24, 400), (4, 3, 20), (5, 26, 3000))]
+    states.append(HostState(np.zeros(60000, dtype=np.uint8)))       # every position collides
+    seeds = [0, 0x7fff, 0x1234, 0x5a5a]
+    for hs, k in zip(states, seeds):
+        hs.st.ins_h = k
+    devs = [DevState(zr, hs) for hs in states]
+    d_views = zr.rocm.views_to_device([d.view for d in devs])
+    ins_h = torch.from_numpy(np.array(seeds, dtype=np.uint32).view(np.int32)).cuda()
+    for (start, count) in plans:
+        strs = torch.full((len(devs),), start, dtype=torch.int32, device="cuda")
+        cnts = torch.full((len(devs),), count, dtype=torch.int32, device="cuda")
+        zr.rocm.insert_string_roll_dev(d_views, len(devs), strs, cnts, ins_h)
+        keys = ins_h.cpu().numpy().view(np.uint32)
+        for i, (hs, d) in enumerate(zip(states, devs)):
+            oracle.oracle_insert_string_roll(hs.ref(), start, count)
+            assert keys[i] == hs.st.ins_h, (start, count, i)
+            assert (d.head_np() == hs.head).all(), (start, count)
+            assert (d.prev_np() == hs.prev).all(), (start, count)
+    for pos in (40000, 40001, 40000, 12):
+        strs = torch.full((len(devs),), pos, dtype=torch.int32, device="cuda")
+        heads = torch.zeros(len(devs), dtype=torch.int16, device="cuda")
+        zr.rocm.quick_insert_string_roll_dev(d_views, len(devs), strs, ins_h, heads)
+        got = heads.cpu().numpy().view(np.uint16)
+        keys = ins_h.cpu().numpy().view(np.uint32)
+        for i, (hs, d) in enumerate(zip(states, devs)):
+            assert got[i] == oracle.oracle_quick_insert_string_roll(hs.ref(), pos)
+            assert keys[i] == hs.st.ins_h
+            assert (d.head_np() == hs.head).all() and (d.prev_np() == hs.prev).all()
+
+
 @pytest.mark.parametrize("level", [1, 3, 4, 6, 9])
 def test_longest_match(zr, oracle, level):
     torch = torch_mod()

@@ -11,19 +11,23 @@ from test_gpu_deflate_prims import DevState
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("level", [7, 8])
+@pytest.mark.parametrize("level", [7, 8, 9])
 def test_longest_match_slow(oracle, level):
     zr = product()
     zr.init()
     torch = torch_mod()
-    data = texty(64000, 500 + level, alphabet=5, words=50)
+    # 32000 positions: no two share a prev[] slot (see test_oracle_match_slow.py)
+    data = texty(32000, 500 + level, alphabet=5, words=50)
     hs = HostState(data)
     hs.set_level(level)
-    oracle.oracle_insert_string(hs.ref(), 0, 63000)
+    if level == 9:                                  # lm_init binds the rolling hash (deflate.c:1223-1234)
+        oracle.oracle_insert_string_roll(hs.ref(), 0, 31700)
+    else:
+        oracle.oracle_insert_string(hs.ref(), 0, 31700)
     dev = DevState(zr, hs)
     rng = np.random.default_rng(level)
     views, curs, wants = [], [], []
-    for strstart in rng.integers(300, 62000, size=500).tolist():
+    for strstart in rng.integers(300, 31000, size=700).tolist():
         cur = int(hs.prev[strstart & hs.st.w_mask])
         if cur == 0 or cur >= strstart or strstart - cur > W_SIZE - 262:
             continue

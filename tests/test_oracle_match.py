@@ -146,3 +146,34 @@ def test_chunkmemset_safe_is_lz77_copy(oracle):
                 assert end == buf.ctypes.data + dist + n
                 assert (buf == model).all()
     assert oracle.oracle_chunksize() == 8
+
+
+def test_rolling_hash_variants(oracle):
+    """insert_string_roll.c (level 9).  The reference holds no vectors for it -> "parity unpinned"; checked against
+    an independent Python model of the template and against the closed form the device kernel uses (after three
+    bytes the key holds exactly those three: (b0 << 10 ^ b1 << 5 ^ b2) & 32767)."""
+    assert oracle.oracle_update_hash_roll(0, 0x61) == 0x61
+    assert oracle.oracle_update_hash_roll(0x7fff, 0x1ff) == ((0x7fff << 5) ^ 0xff) & 32767   # only the low byte counts
+    data = texty(50000, 11)
+    hs = HostState(data)
+    head2, prev2 = hs.head.copy(), hs.prev.copy()
+    ins_h = 0x1234
+    hs.st.ins_h = ins_h
+    for (start, count) in ((0, 1), (1, 1), (2, 63), (65, 64), (129, 1000), (1129, 0), (1129, 30000)):
+        oracle.oracle_insert_string_roll(hs.ref(), start, count)
+        for pos in range(start, start + count):
+            ins_h = ((ins_h << 5) ^ int(hs.window[pos + 2])) & 32767
+            if pos >= 2:
+                b = hs.window[pos:pos + 3].astype(np.uint32)
+                assert ins_h == ((int(b[0]) << 10) ^ (int(b[1]) << 5) ^ int(b[2])) & 32767
+            idx = pos & 0xffff
+            old = int(head2[ins_h])
+            if old != idx:
+                prev2[idx & (W_SIZE - 1)] = old
+                head2[ins_h] = idx
+        assert hs.st.ins_h == ins_h
+        assert (hs.head == head2).all() and (hs.prev == prev2).all()
+    got = oracle.oracle_quick_insert_string_roll(hs.ref(), 40000)
+    want_key = ((ins_h << 5) ^ int(hs.window[40002])) & 32767
+    assert hs.st.ins_h == want_key and got == head2[want_key]
+    assert hs.head[want_key] == 40000 and hs.prev[40000 & (W_SIZE - 1)] == got

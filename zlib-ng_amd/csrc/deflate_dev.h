@@ -41,6 +41,16 @@ __device__ __forceinline__ uint32_t hash_calc(uint32_t val) {
     return ((val * 2654435761u) >> 16) & (kHashSize - 1u);
 }
 
+// insert_string_roll.c:10-24 (level 9): the key is ((h << 5) ^ byte) & 32767 over consecutive bytes, so once three
+// bytes went through it only those three are left in it
+constexpr uint32_t kRollMask = 32767u;
+__device__ __forceinline__ uint32_t hash_roll(uint32_t h, uint32_t byte) {
+    return ((h << 5) ^ (byte & 0xffu)) & kRollMask;
+}
+__device__ __forceinline__ uint32_t hash_roll3(uint32_t b0, uint32_t b1, uint32_t b2) {
+    return ((b0 << 10) ^ (b1 << 5) ^ b2) & kRollMask;
+}
+
 // compare256: first differing byte index of two 256-byte strings (256 if equal).
 // All 64 lanes participate; result is wave-uniform.
 __device__ __forceinline__ uint32_t compare256_wave(const uint8_t *a, const uint8_t *b, int lane) {
@@ -56,14 +66,35 @@ __device__ __forceinline__ uint32_t compare256_wave(const uint8_t *a, const uint
 // insert_string_tpl.h:85-104 for `count` consecutive positions, 64 per pass.
 // Sequential semantics are kept exactly: a position whose hash equals that of an earlier
 // position of the same pass sees that position as the chain head.
-__device__ __forceinline__ void insert_string_wave(const uint8_t *window, uint16_t *head, uint16_t *prev,
-                                                   uint32_t w_mask, uint32_t str, uint32_t count, int lane) {
+// ROLL = the rolling variant (insert_string_roll.c): position str+i is keyed by the bytes at str+i .. str+i+2, except
+// that the first two positions still carry bits of the incoming s->ins_h; returns the key of the last position
+// (the new s->ins_h), or ins_h itself when count is 0.
+template <bool ROLL = false>
+__device__ __forceinline__ uint32_t insert_string_wave(const uint8_t *window, uint16_t *head, uint16_t *prev,
+                                                       uint32_t w_mask, uint32_t str, uint32_t count, int lane,
+                                                       uint32_t ins_h = 0) {
+    uint32_t last_key = ins_h;
     for (uint32_t base = 0; base < count; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const bool live = i < count;
         const uint32_t pos = str + i;
         const uint16_t idx = (uint16_t)pos;                   // `Pos idx` wraps at 16 bits
-        uint32_t h = live ? hash_calc(load_u32(window + pos)) : 0xffffffffu;
+        uint32_t h = 0xffffffffu;
+        if (live) {
+            const uint32_t four = load_u32(window + pos);
+            if (ROLL) {
+                const uint32_t b0 = four & 0xffu, b1 = (four >> 8) & 0xffu, b2 = (four >> 16) & 0xffu;
+                if (i == 0) h = hash_roll(ins_h, b2);
+                else if (i == 1) h = hash_roll(hash_roll(ins_h, b1), b2);
+                else h = hash_roll3(b0, b1, b2);
+            } else {
+                h = hash_calc(four);
+            }
+        }
+        if (ROLL) {
+            const uint32_t tail = count - 1u - base;          // lane of the last position, if in this pass
+            if (tail < 64u) last_key = (uint32_t)__shfl((int)h, (int)tail, 64);
+        }
         // nearest earlier lane with the same hash, and whether a later one exists
         int before = -1;
         bool later = false;
@@ -85,6 +116,7 @@ __device__ __forceinline__ void insert_string_wave(const uint8_t *window, uint16
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0);
     }
+    return last_key;
 }
 
 struct MatchParams {           // the deflate_state fields match_tpl.h reads (deflate.h:164-244)
@@ -140,10 +172,12 @@ __device__ __forceinline__ uint32_t longest_match_wave(const MatchParams &s, uin
     return best_len;
 }
 
-// match_tpl.h:26-280 with LONGEST_MATCH_SLOW (the functable slot `longest_match_slow`, levels 7-8): besides the
+// match_tpl.h:26-280 with LONGEST_MATCH_SLOW (the functable slot `longest_match_slow`, levels 7-9): besides the
 // chain walk it re-anchors the search on the most distant chain among the bytes of the current best match
-// (:94-125, :208-256), using head[] lookups of update_hash over single bytes exactly as the template does with the
-// multiplicative hash (insert_string.c:11-13).  Wave-uniform control flow, wave-wide compare256.
+// (:94-125, :208-256), using head[] lookups of s->update_hash fed byte by byte exactly as the template does:
+// with the multiplicative hash (levels 7-8, insert_string.c:11-13) only the last byte counts, with the rolling
+// hash (ROLL, level 9, insert_string_roll.c) the last three.  Wave-uniform control flow, wave-wide compare256.
+template <bool ROLL>
 __device__ __forceinline__ uint32_t longest_match_slow_wave(const MatchParams &s, const uint16_t *head,
                                                             uint32_t cur_match, uint32_t *match_start_out, int lane) {
     const uint8_t *window = s.window;
@@ -162,7 +196,7 @@ __device__ __forceinline__ uint32_t longest_match_slow_wave(const MatchParams &s
 
     if (best_len >= kStdMinMatch) {
         for (uint32_t i = 3; i <= best_len; ++i) {
-            const uint32_t pos = head[hash_calc(scan[i])];
+            const uint32_t pos = head[ROLL ? hash_roll3(scan[i - 2], scan[i - 1], scan[i]) : hash_calc(scan[i])];
             if (pos < cur_match) {
                 match_offset = i - 2;
                 cur_match = pos;
@@ -202,7 +236,8 @@ __device__ __forceinline__ uint32_t longest_match_slow_wave(const MatchParams &s
                     }
                 }
                 cur_match = next_pos;
-                const uint32_t pos = head[hash_calc(scan[len - (kStdMinMatch + 1) + 2])];
+                const uint8_t *endstr = scan + len - (kStdMinMatch + 1);
+                const uint32_t pos = head[ROLL ? hash_roll3(endstr[0], endstr[1], endstr[2]) : hash_calc(endstr[2])];
                 if (pos < cur_match) {
                     match_offset = len - (kStdMinMatch + 1);
                     if (pos <= limit_base + match_offset) return give_up();

@@ -64,6 +64,13 @@ void update_hash_kernel(const uint32_t *__restrict__ val, size_t n, uint32_t *__
     if (i < n) out[i] = hash_calc(val[i]);
 }
 
+__global__ __launch_bounds__(256)
+void update_hash_roll_kernel(const uint32_t *__restrict__ h, const uint32_t *__restrict__ val, size_t n,
+                             uint32_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hash_roll(h[i], val[i]);
+}
+
 // ---- insert_string family -----------------------------------------------------------
 // QUICK: one position per stream, one LANE per stream (insert_string_tpl.h:58-75).
 __global__ __launch_bounds__(256)
@@ -80,6 +87,38 @@ void quick_insert_kernel(const zng_rocm_deflate_view *__restrict__ views, size_t
         v.head[h] = (uint16_t)pos;
     }
     head_out[i] = head;
+}
+
+// rolling variant (insert_string_roll.c): the key is carried in ins_h[i] (s->ins_h) across calls
+__global__ __launch_bounds__(256)
+void quick_insert_roll_kernel(const zng_rocm_deflate_view *__restrict__ views, size_t nstreams,
+                              const uint32_t *__restrict__ str, uint32_t *__restrict__ ins_h,
+                              uint16_t *__restrict__ head_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstreams) return;
+    const zng_rocm_deflate_view v = views[i];
+    const uint32_t pos = str[i];
+    const uint32_t h = hash_roll(ins_h[i], load_u8(v.window + pos + kStdMinMatch - 1));
+    ins_h[i] = h;
+    const uint16_t head = v.head[h];
+    if ((uint32_t)head != pos) {
+        v.prev[pos & v.w_mask] = head;
+        v.head[h] = (uint16_t)pos;
+    }
+    head_out[i] = head;
+}
+
+__global__ __launch_bounds__(256)
+void insert_string_roll_kernel(const zng_rocm_deflate_view *__restrict__ views, size_t nstreams,
+                               const uint32_t *__restrict__ str, const uint32_t *__restrict__ count,
+                               uint32_t *__restrict__ ins_h) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave >= nstreams) return;
+    const zng_rocm_deflate_view v = views[wave];
+    const uint32_t key = insert_string_wave<true>(v.window, v.head, v.prev, v.w_mask, str[wave], count[wave], lane,
+                                                  ins_h[wave]);
+    if (lane == 0) ins_h[wave] = key;
 }
 
 // one wave per stream
@@ -143,7 +182,10 @@ void longest_match_slow_kernel(const zng_rocm_deflate_view *__restrict__ views, 
     mp.nice_match = (uint32_t)v.nice_match;
     mp.level = v.level;
     uint32_t ms = v.match_start;
-    const uint32_t len = longest_match_slow_wave(mp, v.head, cur_match[wave], &ms, lane);
+    // lm_init binds the rolling update_hash when max_chain_length > 1024, i.e. level 9 (deflate.c:1223-1234)
+    const uint32_t len = v.max_chain_length > 1024u
+                             ? longest_match_slow_wave<true>(mp, v.head, cur_match[wave], &ms, lane)
+                             : longest_match_slow_wave<false>(mp, v.head, cur_match[wave], &ms, lane);
     if (lane == 0) {
         len_out[wave] = len;
         start_out[wave] = ms;
@@ -262,6 +304,38 @@ int zng_rocm_update_hash_dev(const uint32_t *d_val, size_t n, uint32_t *d_hash, 
     if (!d_val || !d_hash) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(update_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_val,
                        n, d_hash);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_update_hash_roll_dev(const uint32_t *d_h, const uint32_t *d_val, size_t n, uint32_t *d_hash, void *stream) {
+    if (int rc = need_ctx()) return rc;
+    if (!n) return ZNG_ROCM_OK;
+    if (!d_h || !d_val || !d_hash) return ZNG_ROCM_EINVAL;
+    hipLaunchKernelGGL(update_hash_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_h, d_val, n, d_hash);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_quick_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                                          uint32_t *d_ins_h, uint16_t *d_head_out, void *stream) {
+    if (int rc = need_ctx()) return rc;
+    if (!nstreams) return ZNG_ROCM_OK;
+    if (!d_views || !d_str || !d_ins_h || !d_head_out) return ZNG_ROCM_EINVAL;
+    hipLaunchKernelGGL(quick_insert_roll_kernel, dim3((unsigned)((nstreams + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_views, nstreams, d_str, d_ins_h, d_head_out);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
+                                    const uint32_t *d_count, uint32_t *d_ins_h, void *stream) {
+    if (int rc = need_ctx()) return rc;
+    if (!nstreams) return ZNG_ROCM_OK;
+    if (!d_views || !d_str || !d_count || !d_ins_h) return ZNG_ROCM_EINVAL;
+    hipLaunchKernelGGL(insert_string_roll_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
+                       d_views, nstreams, d_str, d_count, d_ins_h);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }

@@ -56,6 +56,11 @@ _PROTOS = {
     "zng_rocm_update_hash_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_quick_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zng_rocm_insert_string_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zng_rocm_update_hash_roll_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_quick_insert_string_roll_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p]),
+    "zng_rocm_insert_string_roll_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]),
     "zng_rocm_longest_match_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zng_rocm_longest_match_slow_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]),
@@ -339,6 +344,27 @@ def insert_string_dev(d_views, nstreams, strs, counts, stream=None):
     _need_init()
     _check(lib().zng_rocm_insert_string_dev(_dev_ptr(d_views), nstreams, _dev_ptr(strs), _dev_ptr(counts),
                                             _stream_ptr(stream)), "zng_rocm_insert_string_dev")
+
+
+def update_hash_roll_dev(h, val, out, stream=None):
+    """update_hash_roll (insert_string_roll.c) elementwise over two uint32 arrays"""
+    _need_init()
+    _check(lib().zng_rocm_update_hash_roll_dev(_dev_ptr(h), _dev_ptr(val), val.numel(), _dev_ptr(out),
+                                               _stream_ptr(stream)), "zng_rocm_update_hash_roll_dev")
+
+
+def quick_insert_string_roll_dev(d_views, nstreams, strs, ins_h, head_out, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_quick_insert_string_roll_dev(_dev_ptr(d_views), nstreams, _dev_ptr(strs), _dev_ptr(ins_h),
+                                                       _dev_ptr(head_out), _stream_ptr(stream)),
+           "zng_rocm_quick_insert_string_roll_dev")
+
+
+def insert_string_roll_dev(d_views, nstreams, strs, counts, ins_h, stream=None):
+    _need_init()
+    _check(lib().zng_rocm_insert_string_roll_dev(_dev_ptr(d_views), nstreams, _dev_ptr(strs), _dev_ptr(counts),
+                                                 _dev_ptr(ins_h), _stream_ptr(stream)),
+           "zng_rocm_insert_string_roll_dev")
 
 
 def longest_match_dev(d_views, nstreams, cur_match, len_out, start_out, stream=None):
