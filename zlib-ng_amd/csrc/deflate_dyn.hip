@@ -7,7 +7,8 @@
 //
 //   K1 lz_chain_kernel   one workgroup per segment.  The hash table is primed with the 32 KiB that precede the
 //        segment (what deflateSetDictionary / the sliding window would have left there), then the segment is
-//        parsed with the chain-walking front end of deflate_lz.h (head + prev-delta tables in LDS, 128 KiB).
+//        parsed with the chain-walking front end of deflate_chain.h (head + prev-delta tables AND the 64 KiB
+//        sliding window in LDS, 144.6 KiB).
 //        Matches may reach back into the previous segment: the output is ONE continuous deflate stream.
 //   K2 emit_dynamic_kernel one workgroup per segment = one dynamic-Huffman block: symbol histogram (LDS atomics),
 //        Huffman code lengths (rank sort + two-queue merge, depth limit by frequency halving), canonical codes,
@@ -20,7 +21,7 @@
 // block choice yet); validity is defined by round trip, as in the reference's own tests.
 #include "context.h"
 #include "deflate_dev.h"
-#include "deflate_lz.h"
+#include "deflate_chain.h"
 
 #include <mutex>
 #include <vector>
@@ -36,19 +37,16 @@ struct SegJob {
     uint64_t       sel_off;   // selector index of stream position 0
 };
 
-constexpr int      kChainHashBits = 13;        // 32 KiB head + 64 KiB prev links per segment
 constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block
 constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
 
-constexpr int kChainWaves = 16;                // 1024 lanes walk chains per segment (one segment per CU): the chain walk is
-                                               // latency bound, lanes are what hides it (4 waves 233 ms, 8: 146 ms, 16: 116 ms
-                                               // for 256 MiB at level 6)
-constexpr int kChainBatch = 64 * kChainWaves;
-
+// grid.x = segment.  The plaintext streams through the LDS ring one batch ahead of the parse: 256 lanes fetch the
+// next 1 KiB chunk into a register at the top of a batch and store it into the ring at the top of the next one, so
+// the HBM latency of the fetch is hidden behind a whole batch of chain walking.
 __global__ __launch_bounds__(kChainBatch)
 void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain,
                      uint32_t good_match) {
-    __shared__ LzShared<true, kChainHashBits> sh;
+    __shared__ ChainShared sh;
 
     const SegJob job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
@@ -59,17 +57,39 @@ void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel
     for (int i = t; i < (1 << kChainHashBits); i += kChainBatch) sh.head[i] = 0;
     for (int i = t; i < 32768 / 2; i += kChainBatch) reinterpret_cast<uint32_t *>(sh.prev)[i] = 0;
     if (t == 0) sh.cover = job.seg_start;
-    __syncthreads();
 
     uint32_t P0 = job.seg_start > kPrime ? job.seg_start - kPrime : 0u;
     P0 -= P0 % kChainBatch;
     const uint32_t first = job.seg_start - job.seg_start % kChainBatch;   // batch holding the segment's first byte
-    uint32_t val = P0 + (uint32_t)t + kLzMinMatch <= n ? load_u32(in + P0 + t) : 0u;
+
+    // chunk [F, F + 1024) of the plaintext, one dword per lane of the first four waves; bytes at or beyond n read 0
+    auto fetch = [&](uint32_t F) -> uint32_t {
+        const uint32_t q = F + 4u * (uint32_t)t;
+        if (t >= 256 || q >= n) return 0u;
+        if (q + 4u <= n) return load_u32(in + q);
+        uint32_t v = 0;
+        for (uint32_t j = 0; q + j < n; ++j) v |= (uint32_t)load_u8(in + q + j) << (8u * j);
+        return v;
+    };
+    auto put = [&](uint32_t F, uint32_t v) {
+        if (t < 256) {
+            const uint32_t idx = (F + 4u * (uint32_t)t) & (kRingBytes - 1u);
+            *reinterpret_cast<uint32_t *>(sh.ring + idx) = v;
+            if (idx < kRingMirror) *reinterpret_cast<uint32_t *>(sh.ring + kRingBytes + idx) = v;
+        }
+    };
+    put(P0, fetch(P0));
+    put(P0 + 1024u, fetch(P0 + 1024u));
+    uint32_t chunk = fetch(P0 + 2048u);
+    __syncthreads();
+
     for (uint32_t P = P0; P < n; P += kChainBatch) {
-        const uint32_t pn = P + (uint32_t)kChainBatch + (uint32_t)t;
-        const uint32_t val_next = (pn + kLzMinMatch <= n) ? load_u32(in + pn) : 0u;
+        if (P != P0) {
+            put(P + kRingAhead, chunk);             // [P + 1024, P + 2048): visible after the insert barriers below
+            chunk = fetch(P + kRingAhead + 1024u);
+        }
         const bool prime = P < first;
-        const LzPick r = lz_batch<true, kChainHashBits, kChainWaves>(in, n, P, val, &sh, t, max_chain, prime, good_match);
+        const LzPick r = chain_batch(n, P, &sh, t, max_chain, prime, good_match);
         const uint32_t p = P + (uint32_t)t;
         if (!prime && p >= job.seg_start && p < n) {
             uint32_t s = 0;
@@ -77,7 +97,6 @@ void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel
             else if (r.kind == 1u) s = 0x40000000u;
             sel[p] = s;
         }
-        val = val_next;
     }
 }
 
