@@ -41,7 +41,7 @@ struct StreamJobDev {
 // The next batch's input is prefetched while the current one is parsed.
 __global__ __launch_bounds__(256)
 void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ sel_base) {
-    __shared__ LzShared<false, kQuickHashBits> sh;
+    __shared__ LzShared<kQuickHashBits> sh;
 
     const StreamJobDev job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
@@ -57,7 +57,7 @@ void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
     for (uint32_t P = 0; P < n; P += 256) {
         const uint32_t pn = P + 256u + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
-        const LzPick r = lz_batch<false, kQuickHashBits>(in, n, P, val, &sh, t);
+        const LzPick r = lz_batch<kQuickHashBits>(in, n, P, val, &sh, t);
         const uint32_t p = P + (uint32_t)t;
         if (p < n) {
             uint32_t s = 0;
