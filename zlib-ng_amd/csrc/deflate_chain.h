@@ -174,13 +174,27 @@ __device__ __forceinline__ LzPick chain_batch(uint32_t n, uint32_t P, ChainShare
         // fewer per candidate) are two independent LDS reads, so a trip costs one LDS latency.
         uint32_t tail_off = best - 3;
         uint32_t want_tail = ring_u32(ring, pi + tail_off);          // best < maxlen here
+        uint32_t mine[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = ring_u32(ring, pi + 4u * j);
         if (!(c < p && p - c <= kLzMaxDist)) done = true;
         while (!done) {
             const uint32_t ci = c & (kRingBytes - 1u);
             const uint32_t d = sh->prev[c & 32767u];
             const uint32_t tail = ring_u32(ring, ci + tail_off);
             if (tail == want_tail) {
-                const uint32_t l = ring_common_prefix(ring, p, c, 0, kLzChainProbe, maxlen);
+                uint32_t l;
+                if (maxlen >= 16u) {                    // our first 16 bytes are in registers: read only the candidate's
+                    uint32_t add = 16;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const uint32_t x = ring_u32(ring, ci + 4u * j) ^ mine[j];
+                        if (x) add = 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x) - 1) >> 3);
+                    }
+                    l = add < 16u ? add : ring_common_prefix(ring, p, c, 16, kLzChainProbe, maxlen);
+                } else {
+                    l = ring_common_prefix(ring, p, c, 0, kLzChainProbe, maxlen);
+                }
                 if (l > best) {
                     best = l;
                     dist = p - c;
