@@ -92,13 +92,13 @@ def main():
                     ("crc32", lambda: zr.crc32_dev(big, out, length=n), 1),
                     ("adler32+crc32 fused", lambda: zr.adler32_crc32_dev(big, out, length=n), 1),
                     ("fold_copy (adler+crc, 2N traffic)", lambda: zr.fold_copy_dev(3, dst, big, out, length=n), 2)):
-                for _ in range(3):
+                for _ in range(200):                               # clocks settle
                     fn()
                 torch.cuda.synchronize()
-                zr.trace_begin(20)
-                for _ in range(20):
+                zr.trace_begin(50)
+                for _ in range(50):
                     fn()
-                ms = statistics.mean(zr.trace_end(20))
+                ms = statistics.mean(zr.trace_end(50))
                 step = gpu_time_ms(fn, 10, torch)
                 row[name] = {"kernel_ms": round(ms, 4), "algorithmic_GBps": round(traffic * n / 1e9 / (ms / 1e3), 1),
                              "frac_of_8TBps": round(traffic * n / 1e9 / (ms / 1e3) / 8000, 3),

@@ -84,20 +84,6 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     const int t = threadIdx.x;
     const uint32_t rep = t & 31;
 
-    if constexpr (DO_CRC) {
-        // tables: HBM/L2 -> LDS once (5 KiB, one dwordx4 per lane), then replicated LDS -> LDS:
-        // 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent dwords
-        if (t < 256) {
-            reinterpret_cast<uint4 *>(stage)[t] = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
-        } else if (t < 320) {
-            reinterpret_cast<uint4 *>(stage)[t] = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) lut[i * kWgThreads + t] = stage[i * 32 + (t >> 5)];
-        __syncthreads();
-    }
-
     // contiguous run of units for this workgroup
     const long long G = gridDim.x, g = blockIdx.x;
     const long long q = args.nunits / G, r = args.nunits % G;
@@ -106,6 +92,42 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
 
     // byte offset (relative to a0) of this lane's piece in unit u:  body - (nunits-u)*U + 16t
     long long off = args.body - (args.nunits - u_lo) * (long long)kUnitBytes + (long long)t * kPieceBytes;
+
+    // Main-loop geometry first, so that the first group of HBM loads can be issued BEFORE the tables are built:
+    // their latency then runs under the table build instead of after it.
+    constexpr int UNROLL = 4;
+    const bool head_unit = u_lo < u_hi && u_lo == 0;     // the message's first unit is handled apart (head mask)
+    const long long groups = (u_hi - u_lo - (head_unit ? 1 : 0)) / UNROLL;
+    uint4 bufA[UNROLL], bufB[UNROLL];
+    auto request = [&](uint4 (&buf)[UNROLL], long long at) {
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) buf[j] = ld_stream(args.a0 + at + (long long)j * kUnitBytes);
+    };
+    uint32_t lane_w = 0;                                 // weight of this lane's last dword (epilogue)
+    uint32_t group_w0 = 0, group_w1 = 0;
+    if constexpr (DO_CRC) {
+        // tables: HBM/L2 -> LDS once (5 KiB, one dwordx4 per lane), then replicated LDS -> LDS:
+        // 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent dwords
+        uint4 tab = make_uint4(0, 0, 0, 0);
+        if (t < 256) {
+            tab = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
+        } else if (t < 320) {
+            tab = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
+        }
+        lane_w = tabs->lane_weight[t][3];
+        // the two digits of this group's end-of-body weight (epilogue, thread 0): fetched now, not on the tail
+        const unsigned long long k_after = (unsigned long long)(args.nunits - u_hi);
+        group_w0 = tabs->unit_pow[0][k_after & 1023u];
+        group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
+        if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
+        if (t < 320) reinterpret_cast<uint4 *>(stage)[t] = tab;
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) lut[i * kWgThreads + t] = stage[i * 32 + (t >> 5)];
+        __syncthreads();
+    } else {
+        if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
+    }
 
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;             // CRC braids
     uint32_t S1 = 0, SR = 0, SW = 0;                     // Adler: byte sum, prefix-of-sums, in-piece weights
@@ -169,15 +191,8 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     // Main loop, software pipelined with two register buffers (ping-pong, no copies): while group k is
     // consumed the UNROLL rows of group k+1 are already in flight, so every lane keeps UNROLL..2*UNROLL
     // dwordx4 loads outstanding (16 waves x 4..8 KiB per CU) and each wait is a counted vmcnt(UNROLL).
-    constexpr int UNROLL = 4;
     constexpr int BATCH_MAX = 240;     // u32 bounds: SR <= 4080 * 240*239/2 < 2^27
-    const long long groups = (u_hi - u) / UNROLL;
     if (groups > 0) {
-        uint4 bufA[UNROLL], bufB[UNROLL];
-        auto request = [&](uint4 (&buf)[UNROLL], long long at) {
-#pragma unroll
-            for (int j = 0; j < UNROLL; ++j) buf[j] = ld_stream(args.a0 + at + (long long)j * kUnitBytes);
-        };
         auto retire = [&](uint4 (&buf)[UNROLL]) {
             if constexpr (COPY) {
 #pragma unroll
@@ -193,8 +208,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             }
         };
         const long long gstride = (long long)UNROLL * kUnitBytes;
-        request(bufA, off);
-        long long k = 0;
+        long long k = 0;                                   // group 0 is already in flight (issued above)
         while (k + 2 < groups) {                           // steady state: no conditional loads, counted waits
             request(bufB, off + gstride);                  // group k+1
             __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +254,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
                 for (int k = 0; k < 4; ++k) r = bt[r & 0xffu] ^ (r >> 8);
                 r ^= c == 0 ? s1 : (c == 1 ? s2 : s3);
             }
-            uint32_t b = tabs->lane_weight[t][3];
+            uint32_t b = lane_w;
 #pragma unroll 1
             for (int i = 31; i >= 0; --i) {
                 pc ^= b & (0u - ((r >> i) & 1u));
@@ -277,8 +291,8 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
         if constexpr (DO_CRC) {
             const unsigned long long k = (unsigned long long)(args.nunits - u_hi);
             if (c && k) {
-                c = mulmod(c, tabs->unit_pow[0][k & 1023u]);
-                if (k >> 10) c = mulmod(c, tabs->unit_pow[1][(k >> 10) & 1023u]);
+                c = mulmod(c, group_w0);
+                if (k >> 10) c = mulmod(c, group_w1);
             }
         }
         Partial pt;
