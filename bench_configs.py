@@ -107,6 +107,43 @@ def main():
         report["cfg2"] = rows
         del big, dst
 
+        # CPU side of cfg2 on this box's host cores: 1 thread, and T threads each on its own
+        # contiguous slice, folded with the combine operators.  adler32 = the oracle port of adler32_c.c, crc32 = the
+        # reference's crc32_braid_c.c (oracle/_ref) when present, else the oracle port.
+        import threading
+        n = 256 << 20
+        host = np.frombuffer(np.random.default_rng(2).bytes(n), dtype=np.uint8)
+        crc_fn = ref_crc if ref_crc is not None else orc.oracle_crc32
+        cpu_rows = {}
+        for T in (1, min(64, os.cpu_count() or 1)):
+            cuts = [n * k // T for k in range(T + 1)]
+            part = [None] * T
+
+            def work(k):
+                p, ln = host.ctypes.data + cuts[k], cuts[k + 1] - cuts[k]
+                part[k] = (orc.oracle_adler32(1, p, ln), crc_fn(0, p, ln), ln)
+
+            best = None
+            for _ in range(3):
+                ths = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+                t0 = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                a, c = part[0][0], part[0][1]
+                for k in range(1, T):
+                    a = zr.rocm.adler32_combine(a, part[k][0], part[k][2])
+                    c = zr.rocm.crc32_combine(c, part[k][1], part[k][2])
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            cpu_rows["threads_%d" % T] = {"adler32_plus_crc32_GBps": round(n / 1e9 / best, 2), "adler": a, "crc": c}
+        same = len({(v["adler"], v["crc"]) for v in cpu_rows.values()}) == 1
+        report["cfg2_cpu"] = {"sample": "256 MiB, adler32 then crc32 per slice, best of 3", "kind":
+                              "reference crc32_braid_c.c + oracle adler32" if ref_crc is not None else "oracle port",
+                              "slices_combine_to_same_value": same,
+                              **{k: v["adler32_plus_crc32_GBps"] for k, v in cpu_rows.items()}}
+
     # ---- chunkset: the inflate copy primitive as a batch of independent copies (north_star's third kernel) ----
     # Outputs tile one region back to back (as inflate's output does); sources are drawn from another region.
     # Algorithmic bytes per copy: len read + len written + 24 of descriptors.

@@ -216,3 +216,37 @@ def test_slots_from_concurrent_host_threads(zr, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_beyond_4gib(zr, oracle):
+    """size_t lengths: 5 GiB + 12345 bytes in one call (every 32-bit byte count or offset would wrap).  Checked
+    against the oracle on the host and, independently, against the device combine of three ragged parts."""
+    torch = torch_mod()
+    n = (5 << 30) + 12345
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x5EED0009)
+    d = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+    step = 1 << 30
+    for lo in range(0, n + 16, step):                       # filled in 1 GiB pieces: randint temporaries stay small
+        hi = min(n + 16, lo + step)
+        d[lo:hi] = torch.randint(0, 256, (hi - lo,), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zr.adler32_crc32_dev(d, out, adler=1, crc=0, length=n, offset=5)
+    got = [v & 0xffffffff for v in out.tolist()]
+    edges = [0, (1 << 32) + 77, (1 << 32) + 78, n]          # one part longer than 4 GiB, one of a single byte
+    a_chk = torch.zeros(3, dtype=torch.int32, device="cuda")
+    c_chk = torch.zeros(3, dtype=torch.int32, device="cuda")
+    tmp = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for i in range(3):
+        zr.adler32_crc32_dev(d, tmp, length=edges[i + 1] - edges[i], offset=5 + edges[i])
+        a_chk[i], c_chk[i] = tmp[0], tmp[1]
+    d_lens = torch.tensor(np.diff(np.array(edges, dtype=np.int64)), device="cuda")
+    zr.adler32_combine_dev(a_chk, d_lens, tmp)
+    ca = tmp[0].item() & 0xffffffff
+    zr.crc32_combine_dev(c_chk, d_lens, tmp)
+    assert [ca, tmp[0].item() & 0xffffffff] == got
+    host = d[5:5 + n].cpu().numpy()
+    assert got[0] == oracle.oracle_adler32(1, host.ctypes.data, n)
+    assert got[1] == oracle.oracle_crc32(0, host.ctypes.data, n)
+    # host-pointer slot with a > 4 GiB buffer (PCIe staging inside)
+    assert zr.crc32_z(0, host) == got[1]
