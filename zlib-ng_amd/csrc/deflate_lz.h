@@ -124,34 +124,42 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     // 3a. speculative parse of this wave's region [w0, w0 + lim)
     const uint32_t w0 = P + 64u * (uint32_t)wave;
     const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
-    const unsigned long long M = __ballot(len >= kLzMinMatch);
-    unsigned long long starts = 0;                       // token starts (literals and matches)
-    unsigned long long mstarts = 0;                      // the starts that are matches
-    uint32_t pos = 0, last_start = kLzNone;
-    while (pos < lim) {
-        const unsigned long long rest = M >> pos;
-        if (rest == 0) {                                 // literals to the end of the region
-            starts |= lz_bits_below(lim) & ~lz_bits_below(pos);
-            pos = lim;
-            last_start = kLzNone;
-            break;
-        }
-        const uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
+    // This loop is scalar code, and the scalar unit is what bounds the kernel (rocprofv3 counters: 364 SALU against
+    // 127 VALU instructions per 64 positions before this form) -- so it is written to stay short: no 64-bit selects,
+    // every shift count below 64 by construction, the covered-bytes mask instead of per-run literal masks.
+    const unsigned long long limmask = lz_bits_below(lim);
+    unsigned long long avail = __ballot(len >= kLzMinMatch) & limmask;   // matches not yet hopped over
+    unsigned long long covered = 0;                      // bytes inside a chosen match, behind its first byte
+    unsigned long long mstarts = 0;                      // chosen matches
+    uint32_t last_m = 0, end = 0;                        // the last chosen match and the first byte after it
+    while (avail) {
+        const uint32_t m = (uint32_t)__builtin_ctzll(avail);
         uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
-        starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
-        mstarts |= 1ull << m;
-        const uint32_t pabs = w0 + m;
-        const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-        if (L >= kLzProbe && L < maxlen) {
-            const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
-            uint32_t rem = maxlen - L;
-            if (rem > 256u) rem = 256u;
-            L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
-            if ((uint32_t)lane == m) len = L;
+        if (L >= kLzProbe) {                             // the probe saturated: measure the rest wave-wide
+            const uint32_t pabs = w0 + m;
+            const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
+            if (L < maxlen) {
+                const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
+                uint32_t rem = maxlen - L;
+                if (rem > 256u) rem = 256u;
+                L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
+                if ((uint32_t)lane == m) len = L;
+            }
         }
-        last_start = pabs;
-        pos = m + L;
+        mstarts |= 1ull << m;
+        last_m = m;
+        end = m + L;
+        if (end >= lim) break;                           // lim <= 64: every shift below is by less than 64
+        covered |= (~0ull << (m + 1u)) & ~(~0ull << end);
+        avail &= ~0ull << end;
     }
+    uint32_t pos = lim, last_start = kLzNone;            // literals to the end of the region ...
+    if (end >= lim && mstarts) {                         // ... unless its last token is a match
+        pos = end;
+        last_start = w0 + last_m;
+        if (last_m < 63u) covered |= ~0ull << (last_m + 1u);
+    }
+    const unsigned long long starts = ~covered & limmask;   // token starts: literals and matches
     if (lane == 0) {
         sh->last_start[wave] = last_start;
         sh->exit_pos[wave] = w0 + pos;
