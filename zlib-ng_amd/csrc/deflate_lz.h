@@ -74,13 +74,16 @@ struct LzPick {
 
 // One batch of the level-1 class: a single chain-head probe per position (deflate_quick.c:89-97).
 // `val` = the 4 bytes at this lane's position (0 if fewer remain).
-template <int HBITS, int NW = 4>   // NW = wavefronts per workgroup (batch = 64 * NW positions)
+// FULL: the caller guarantees that every position of the batch has its whole 258-byte lookahead inside the stream
+// (all batches but the last two of a stream) -- lim, maxlen and the end-of-input guards fold to constants, which
+// matters because the scalar instructions they cost are the kernel's bound.
+template <int HBITS, int NW = 4, bool FULL = false>   // NW = wavefronts per workgroup (batch = 64 * NW positions)
 __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
                                            LzShared<HBITS> *sh, int t) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
-    const bool can = p + kLzMinMatch <= n;              // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
+    const bool can = FULL || p + kLzMinMatch <= n;      // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
     const uint32_t h = lz_hash<HBITS>(val);
 
     // 1. insert, waves in position order
@@ -92,7 +95,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
 
     // 2. probe
     uint32_t len = 0, dist = 0;
-    const uint32_t maxlen = p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u;
+    const uint32_t maxlen = FULL ? kStdMaxMatch : (p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u);
     {
         if (old) {
             const uint32_t c = old - 1u;
@@ -123,30 +126,28 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
 
     // 3a. speculative parse of this wave's region [w0, w0 + lim)
     const uint32_t w0 = P + 64u * (uint32_t)wave;
-    const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
+    const uint32_t lim = FULL ? 64u : (w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u));
     // This loop is scalar code, and the scalar unit is what bounds the kernel (rocprofv3 counters: 364 SALU against
     // 127 VALU instructions per 64 positions before this form) -- so it is written to stay short: no 64-bit selects,
     // every shift count below 64 by construction, the covered-bytes mask instead of per-run literal masks.
-    const unsigned long long limmask = lz_bits_below(lim);
+    const unsigned long long limmask = FULL ? ~0ull : lz_bits_below(lim);
     unsigned long long avail = __ballot(len >= kLzMinMatch) & limmask;   // matches not yet hopped over
     unsigned long long covered = 0;                      // bytes inside a chosen match, behind its first byte
-    unsigned long long mstarts = 0;                      // chosen matches
-    uint32_t last_m = 0, end = 0;                        // the last chosen match and the first byte after it
+    uint32_t last_m = 64u, end = 0;                      // the last chosen match and the first byte after it
     while (avail) {
         const uint32_t m = (uint32_t)__builtin_ctzll(avail);
         uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
         if (L >= kLzProbe) {                             // the probe saturated: measure the rest wave-wide
             const uint32_t pabs = w0 + m;
-            const uint32_t maxlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-            if (L < maxlen) {
+            const uint32_t mlen = FULL ? kStdMaxMatch : ((n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch);
+            if (L < mlen) {
                 const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
-                uint32_t rem = maxlen - L;
+                uint32_t rem = mlen - L;
                 if (rem > 256u) rem = 256u;
                 L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
                 if ((uint32_t)lane == m) len = L;
             }
         }
-        mstarts |= 1ull << m;
         last_m = m;
         end = m + L;
         if (end >= lim) break;                           // lim <= 64: every shift below is by less than 64
@@ -154,11 +155,14 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         avail &= ~0ull << end;
     }
     uint32_t pos = lim, last_start = kLzNone;            // literals to the end of the region ...
-    if (end >= lim && mstarts) {                         // ... unless its last token is a match
+    unsigned long long mstarts = 0;                      // chosen matches: the byte before a covered run ...
+    if (end >= lim && last_m < 64u) {                    // ... unless its last token is a match
         pos = end;
         last_start = w0 + last_m;
         if (last_m < 63u) covered |= ~0ull << (last_m + 1u);
+        else mstarts = 1ull << 63;                       // ... and a match that starts on the region's last byte
     }
+    mstarts |= ~covered & (covered >> 1);
     const unsigned long long starts = ~covered & limmask;   // token starts: literals and matches
     if (lane == 0) {
         sh->last_start[wave] = last_start;
@@ -173,7 +177,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         if (v == wave) cover = carry;
         const uint32_t ls = sh->last_start[v], ex = sh->exit_pos[v];
         const uint32_t region_end = P + 64u * (uint32_t)(v + 1);
-        const uint32_t lim_end = region_end < n ? region_end : n;
+        const uint32_t lim_end = FULL ? region_end : (region_end < n ? region_end : n);
         const bool kept = ls == kLzNone || ls >= carry;            // the region's last token survives the cover
         const uint32_t out = kept ? ex : lim_end;
         carry = carry > out ? carry : out;
@@ -185,7 +189,7 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
     r.kind = 0;
     r.len = len;
     r.dist = dist;
-    if (p < n && p >= cover) {
+    if ((FULL || p < n) && p >= cover) {
         if ((starts >> lane) & 1ull) {
             r.kind = ((mstarts >> lane) & 1ull) ? 2u : 1u;
         } else {

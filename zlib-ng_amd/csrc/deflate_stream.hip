@@ -57,7 +57,10 @@ void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
     for (uint32_t P = 0; P < n; P += 256) {
         const uint32_t pn = P + 256u + (uint32_t)t;
         const uint32_t val_next = (pn + kLzMinMatch <= n && pn >= P) ? load_u32(in + pn) : 0u;   // prefetch
-        const LzPick r = lz_batch<kQuickHashBits>(in, n, P, val, &sh, t);
+        // every position of the batch has its whole lookahead inside the stream: the guard-free instantiation
+        const bool full = n >= 256u + kStdMaxMatch + 4u && P <= n - (256u + kStdMaxMatch + 4u);
+        const LzPick r = full ? lz_batch<kQuickHashBits, 4, true>(in, n, P, val, &sh, t)
+                              : lz_batch<kQuickHashBits, 4, false>(in, n, P, val, &sh, t);
         const uint32_t p = P + (uint32_t)t;
         if (p < n) {
             uint32_t s = 0;
