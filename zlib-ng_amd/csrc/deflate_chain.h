@@ -223,20 +223,14 @@ __device__ __forceinline__ LzPick chain_batch(uint32_t n, uint32_t P, ChainShare
     // 3a. speculative parse of this wave's region [w0, w0 + lim)
     const uint32_t w0 = P + 64u * (uint32_t)wave;
     const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
-    const unsigned long long M = __ballot(len >= kLzMinMatch);
-    unsigned long long starts = 0;                       // token starts (literals and matches)
-    unsigned long long mstarts = 0;                      // the starts that are matches (lazy evaluation can demote a lane
-                                                         // with len >= 4 to a literal)
-    uint32_t pos = 0, last_start = kLzNone;
-    while (pos < lim) {
-        const unsigned long long rest = M >> pos;
-        if (rest == 0) {                                 // literals to the end of the region
-            starts |= lz_bits_below(lim) & ~lz_bits_below(pos);
-            pos = lim;
-            last_start = kLzNone;
-            break;
-        }
-        uint32_t m = pos + (uint32_t)(__ffsll((long long)rest) - 1);
+    // Scalar code, kept short (see deflate_lz.h: the scalar unit is the first thing such a loop saturates): no 64-bit
+    // selects, every shift count below 64 by construction, a covered-bytes mask instead of per-run literal masks.
+    const unsigned long long limmask = lz_bits_below(lim);
+    unsigned long long avail = __ballot(len >= kLzMinMatch) & limmask;   // matches not yet hopped over
+    unsigned long long covered = 0;                      // bytes inside a chosen match, behind its first byte
+    uint32_t last_m = 64u, end = 0;                      // the last chosen match and the first byte after it
+    while (avail) {
+        uint32_t m = (uint32_t)__builtin_ctzll(avail);
         uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
         // lazy evaluation: a strictly longer match one byte later turns this byte into a literal
         while (L < 16u && m + 1u < lim) {
@@ -245,20 +239,33 @@ __device__ __forceinline__ LzPick chain_batch(uint32_t n, uint32_t P, ChainShare
             ++m;
             L = L2;
         }
-        starts |= lz_bits_below(m + 1) & ~lz_bits_below(pos);          // literals [pos, m) and the match start m
-        mstarts |= 1ull << m;
-        const uint32_t pabs = w0 + m;
-        const uint32_t mlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
-        if (L >= kLzChainProbe && L < mlen) {
-            const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
-            uint32_t rem = mlen - L;
-            if (rem > 256u) rem = 256u;
-            L += ring_extend_wave(ring, pabs + L, pabs - D + L, rem, lane);
-            if ((uint32_t)lane == m) len = L;
+        if (L >= kLzChainProbe) {                        // the probe saturated: measure the rest wave-wide
+            const uint32_t pabs = w0 + m;
+            const uint32_t mlen = (n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch;
+            if (L < mlen) {
+                const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
+                uint32_t rem = mlen - L;
+                if (rem > 256u) rem = 256u;
+                L += ring_extend_wave(ring, pabs + L, pabs - D + L, rem, lane);
+                if ((uint32_t)lane == m) len = L;
+            }
         }
-        last_start = pabs;
-        pos = m + L;
+        last_m = m;
+        end = m + L;
+        if (end >= lim) break;                           // lim <= 64: every shift below is by less than 64
+        covered |= (~0ull << (m + 1u)) & ~(~0ull << end);
+        avail &= ~0ull << end;
     }
+    uint32_t pos = lim, last_start = kLzNone;            // literals to the end of the region ...
+    unsigned long long mstarts = 0;                      // chosen matches: the byte before a covered run ...
+    if (end >= lim && last_m < 64u) {                    // ... unless its last token is a match
+        pos = end;
+        last_start = w0 + last_m;
+        if (last_m < 63u) covered |= ~0ull << (last_m + 1u);
+        else mstarts = 1ull << 63;                       // ... and a match that starts on the region's last byte
+    }
+    mstarts |= ~covered & (covered >> 1);
+    const unsigned long long starts = ~covered & limmask;   // token starts: literals and matches
     if (lane == 0) {
         sh->last_start[wave] = last_start;
         sh->exit_pos[wave] = w0 + pos;
