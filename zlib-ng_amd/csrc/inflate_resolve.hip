@@ -43,10 +43,10 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
     uint8_t *lit = lit_all[w];
     const uint64_t t0 = segs[3 * seg], t1 = segs[3 * seg + 3];
     const long long o0 = (long long)segs[3 * seg + 1];
-    long long op = o0, flushed = o0;
+    uint16_t *out = sym + o0;                // positions below are RELATIVE to the segment's first symbol (32 bit):
+    uint32_t op = 0, flushed = 0;            // a segment holds < 33 KiB, a source reaches at most 32 KiB before it
     unsigned long long lp = segs[3 * seg + 2];
     unsigned long long lit_base = lp;
-    const long long ctx_base = o0 - kCtx;
 
     auto stage_literals = [&]() {            // lit[] <- literals[lit_base .. lit_base + kLitWin)
         const unsigned long long at = lit_base + 16ull * (unsigned long long)lane;
@@ -60,13 +60,19 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
             }
         }
     };
-    auto flush = [&](long long upto) {       // symbols [flushed, upto) ring -> HBM, coalesced
-        for (long long i = flushed + lane; i < upto; i += 64) sym[i] = ring[i & (kRing - 1)];
+    auto flush = [&](uint32_t upto) {        // symbols [flushed, upto) ring -> HBM, coalesced
+        for (uint32_t i = flushed + (uint32_t)lane; i < upto; i += 64) out[i] = ring[i & (kRing - 1)];
         flushed = upto;
         // a later match may read these symbols back from HBM: have the stores acknowledged first
         // (once per 2048 symbols, not once per token)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0);
+    };
+    // symbol at relative position rp (may be negative: the 32 KiB before the segment)
+    auto fetch = [&](int rp) -> uint16_t {
+        if (rp >= (int)flushed) return ring[(uint32_t)rp & (kRing - 1)];
+        if (rp >= 0) return out[rp];
+        return (uint16_t)(256 + (int)kCtx + rp);
     };
 
     stage_literals();
@@ -75,6 +81,7 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
         const int cnt = (int)((t1 - base) < 64 ? (t1 - base) : 64);
         for (int j = 0; j < cnt; ++j) {
             const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)mytok, j);
+            if (op - flushed >= kFlush) flush(flushed + kFlush);
             if (!(tok >> 31)) {
                 uint32_t n = tok;
                 while (n) {
@@ -85,7 +92,8 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
                         stage_literals();
                         avail = kLitWin;
                     }
-                    const uint32_t chunk = n < avail ? n : avail;
+                    uint32_t chunk = n < avail ? n : avail;
+                    if (chunk > kFlush) chunk = kFlush;           // the ring keeps kRing - kFlush unflushed symbols
                     const uint32_t lo = (uint32_t)(lp - lit_base);
                     for (uint32_t i = (uint32_t)lane; i < chunk; i += 64)
                         ring[(op + i) & (kRing - 1)] = lit[lo + i];
@@ -94,26 +102,26 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
                     n -= chunk;
                 }
             } else {
-                if (op - flushed >= kFlush) flush(flushed + kFlush);
+                // len, dist and op are wave-uniform: the shape of the copy is decided by scalar branches.  Every
+                // source symbol of a match was produced before the token started (with dist < len the sources are
+                // the `dist` symbols before op, replicated), so the rounds of a copy are independent of each other.
                 const uint32_t len = ((tok >> 16) & 0xffu) + 3u;
                 const uint32_t dist = (tok & 0xffffu) + 1u;
-                const long long src = op - (long long)dist;
-                uint16_t v[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                    v[k] = 0;
-                    if (i < len) {
-                        const long long p = src + (long long)(dist < len ? i % dist : i);
-                        if (p >= flushed) v[k] = ring[p & (kRing - 1)];
-                        else if (p >= o0) v[k] = sym[p];
-                        else v[k] = (uint16_t)(256 + (p - ctx_base));
+                const int src = (int)op - (int)dist;
+                if (dist >= len) {
+                    if (src >= (int)flushed) {                    // the common case: ring to ring
+                        for (uint32_t i = (uint32_t)lane; i < len; i += 64)
+                            ring[(op + i) & (kRing - 1)] = ring[((uint32_t)src + i) & (kRing - 1)];
+                    } else {
+                        for (uint32_t i = (uint32_t)lane; i < len; i += 64)
+                            ring[(op + i) & (kRing - 1)] = fetch(src + (int)i);
                     }
-                }
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-                    if (i < len) ring[(op + i) & (kRing - 1)] = v[k];
+                } else if (dist == 1u) {                          // a run of one symbol
+                    const uint16_t v = fetch(src);
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) ring[(op + i) & (kRing - 1)] = v;
+                } else {
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64)
+                        ring[(op + i) & (kRing - 1)] = fetch(src + (int)(i % dist));
                 }
                 op += len;
             }
