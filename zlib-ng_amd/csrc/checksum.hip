@@ -103,7 +103,6 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) buf[j] = ld_stream(args.a0 + at + (long long)j * kUnitBytes);
     };
-    uint32_t lane_w = 0;                                 // weight of this lane's last dword (epilogue)
     uint32_t group_w0 = 0, group_w1 = 0;
     if constexpr (DO_CRC) {
         // tables: HBM/L2 -> LDS once (5 KiB, one dwordx4 per lane), then replicated LDS -> LDS:
@@ -114,7 +113,6 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
         } else if (t < 320) {
             tab = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
         }
-        lane_w = tabs->lane_weight[t][3];
         // the two digits of this group's end-of-body weight (epilogue, thread 0): fetched now, not on the tail
         const unsigned long long k_after = (unsigned long long)(args.nunits - u_hi);
         group_w0 = tabs->unit_pow[0][k_after & 1023u];
@@ -122,8 +120,12 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
         if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
         if (t < 320) reinterpret_cast<uint4 *>(stage)[t] = tab;
         __syncthreads();
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) lut[i * kWgThreads + t] = stage[i * 32 + (t >> 5)];
+        // entry e sits in lut[32 e .. 32 e + 31]: eight lanes write one entry, four replicas (one b128) each
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t v = stage[i * 128 + (t >> 3)];
+            reinterpret_cast<uint4 *>(lut)[i * kWgThreads + t] = make_uint4(v, v, v, v);
+        }
         __syncthreads();
     } else {
         if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
@@ -254,12 +256,14 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
                 for (int k = 0; k < 4; ++k) r = bt[r & 0xffu] ^ (r >> 8);
                 r ^= c == 0 ? s1 : (c == 1 ? s2 : s3);
             }
-            uint32_t b = lane_w;
-#pragma unroll 1
-            for (int i = 31; i >= 0; --i) {
-                pc ^= b & (0u - ((r >> i) & 1u));
-                b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));
-            }
+            // r * (this lane's weight): the 32 partial products weight * x^k come from a table (32 lane-consecutive
+            // loads in flight together) instead of a 32-step shift-and-reduce loop -- that loop was 3.1 of the 7.5 us
+            // a CRC launch costs beyond its streaming time.  Bit 31 of r is the x^0 coefficient.
+            uint32_t part[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) pc ^= part[k] & (0u - ((r >> (31 - k)) & 1u));
         }
     }
     uint32_t pa = (uint32_t)accA, pb = (uint32_t)accB;

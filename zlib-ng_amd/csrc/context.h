@@ -24,6 +24,8 @@ struct DeviceTables {
     uint32_t lane_weight[kWgThreads][4]; // word c of lane t -> x^(8*(kUnitBytes - 16t - 4c)): distance to unit end
     uint32_t pow_tab[kPowDigits * 128];  // x^(8 * digit * 128^i), see gf2.h xpow_bytes
     uint32_t unit_pow[2][1024];          // x^(8 * kUnitBytes * d * 1024^i): weight of "d units later", two 10-bit digits
+    uint32_t lane_pow[32][kWgThreads];   // lane_weight[t][3] * x^k, k = 0..31 (k-major: lane-consecutive loads): the 32
+                                         //   partial products of the epilogue's per-lane GF(2) multiply, precomputed
 };
 
 struct Partial {            // one per workgroup, written by the streaming kernel

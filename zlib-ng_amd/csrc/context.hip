@@ -61,6 +61,13 @@ static void build_tables(DeviceTables &t) {
                 cur = mulmod(cur, x32);
             }
     }
+    for (int lane = 0; lane < kWgThreads; ++lane) {
+        uint32_t b = t.lane_weight[lane][3];
+        for (int k = 0; k < 32; ++k) {
+            t.lane_pow[k][lane] = b;
+            b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));                  // times x, reflected representation
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         uint32_t step = xpow_bits(8ull * (uint64_t)kUnitBytes << (10 * i));   // x^(8 * U * 1024^i)
         uint32_t cur = 0x80000000u;
