@@ -71,3 +71,38 @@ def test_ratio_is_level6_class(mods):
     z1 = len(zlib.compress(data.tobytes(), 1))
     print("ratio dev6 %.3f  zlib6 %.3f  zlib1 %.3f" % (data.size / clen, data.size / z6, data.size / z1))
     assert clen < 1.12 * z6
+
+
+def test_block_type_choice(mods):
+    """zng_tr_flush_block's choice (trees.c:660-719) per segment: incompressible bytes are STORED (5 bytes per 65535),
+    a few bytes take the STATIC code set, ordinary data a dynamic block.  BTYPE is bits 1-2 of a block's first byte."""
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    rng = np.random.default_rng(77)
+
+    def run(data):
+        src = torch.from_numpy(np.frombuffer(data + b"\0" * 16, dtype=np.uint8).copy()).cuda()
+        dst, clen = dfl.deflate_dev(src, level=6, length=len(data))
+        comp = dst[:clen].cpu().numpy().tobytes()
+        d = zlib.decompressobj(-15)
+        assert d.decompress(comp) == data and d.eof
+        dec = inf.decode_tokens(comp)
+        assert dec.status == 1 and inf.resolve_dev(dec).cpu().numpy().tobytes() == data
+        return comp
+
+    noise = rng.integers(0, 256, size=(1 << 20) + 777, dtype=np.uint8).tobytes()     # two full segments + a tail
+    comp = run(noise)
+    nblocks = sum((n + 65534) // 65535 for n in (512 << 10, 512 << 10, 777))
+    assert len(comp) == len(noise) + 5 * nblocks + 2                    # + the final empty static block
+    assert (comp[0] >> 1) & 3 == 0 and comp[1:3] == (65535).to_bytes(2, "little")
+    for data in (b"", b"q", b"abcabcabcabc"):
+        comp = run(data)
+        assert (comp[0] >> 1) & 3 == 1, data                              # static
+        assert len(comp) <= len(zlib.compress(data, 6)) + 8
+    text = (b"the quick brown fox jumps over the lazy dog, " * 3000)
+    comp = run(text)
+    assert (comp[0] >> 1) & 3 == 2                                        # dynamic
+    # a stream whose segments differ: noise, then text, then noise
+    mixed = noise[:512 << 10] + (text * 4)[:512 << 10] + noise[:300000]
+    comp = run(mixed)
+    assert len(comp) < len(mixed) - 400000

@@ -17,8 +17,9 @@
 //        byte aligned (what Z_SYNC_FLUSH emits, deflate.c:1064-1076); the last one appends the final empty
 //        static block.  K3 packs the segments back to back.
 //
-// Not bit-identical to the reference's stream (different parse, one block per segment, no stored/static
-// block choice yet); validity is defined by round trip, as in the reference's own tests.
+// Per segment the block type is chosen as zng_tr_flush_block does (trees.c:660-719): stored if that is not larger,
+// else static if not larger than dynamic.  Not bit-identical to the reference's stream (different parse, one block
+// per segment); validity is defined by round trip, as in the reference's own tests.
 #include "context.h"
 #include "deflate_dev.h"
 #include "deflate_chain.h"
@@ -120,6 +121,10 @@ struct DynTables {                 // LDS
     uint8_t  cllen[19];
     uint16_t clcode[19];
     uint32_t ncl, hlit, hdist, hclen;
+    // block-type choice (zng_tr_flush_block, trees.c:660-719)
+    uint32_t lfreq0[288], dfreq0[32];     // the histograms as counted (the tree builder may rescale its inputs)
+    uint32_t cost_dyn, cost_static;       // body bits under the dynamic / the static codes
+    uint32_t mode;                        // 0 = dynamic, 1 = static, 2 = stored
 };
 
 // Code lengths (<= maxbits) for freq[0..n) into len[0..n).  All 256 lanes call it; serial parts run on lane 0.
@@ -296,6 +301,9 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
     }
     if (t == 0) atomicAdd(&T.lfreq[256], 1u);           // end-of-block
     __syncthreads();
+    for (int i = t; i < 288; i += 256) T.lfreq0[i] = T.lfreq[i];
+    if (t < 32) T.dfreq0[t] = T.dfreq[t];
+    if (t == 0) T.cost_dyn = T.cost_static = 0;
 
     // 2. code lengths and codes
     huff_lengths(&T, T.lfreq, 286, 15, T.llen, t);
@@ -346,25 +354,105 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
     huff_lengths(&T, T.clfreq, 19, 7, T.cllen, t);
     huff_codes(T.cllen, 19, T.clcode, t);
 
-    // 4. header bits, serial (a few hundred bits)
+    // 3b. which block type?  Body cost under both code sets from the histograms (extra bits included), the
+    //     dynamic header from its run-length form, the stored size exactly -- the comparison zng_tr_flush_block
+    //     makes (trees.c:660-719: stored if not larger, else static if not larger than dynamic, else dynamic).
+    {
+        uint32_t cd = 0, cs = 0;
+        for (int sy = t; sy < 286; sy += 256) {
+            const uint32_t f = T.lfreq0[sy];
+            if (f) {
+                const uint32_t eb = (sy < 265 || sy == 285) ? 0u : (uint32_t)(sy - 261) >> 2;
+                const uint32_t sl = sy < 144 ? 8u : (sy < 256 ? 9u : (sy < 280 ? 7u : 8u));   // RFC 1951 3.2.6
+                cd += f * (T.llen[sy] + eb);
+                cs += f * (sl + eb);
+            }
+        }
+        if (t < 30) {
+            const uint32_t f = T.dfreq0[t];
+            const uint32_t eb = t < 4 ? 0u : ((uint32_t)t >> 1) - 1u;
+            cd += f * (T.dlen[t] + eb);
+            cs += f * (5u + eb);
+        }
+        if (cd) atomicAdd(&T.cost_dyn, cd);
+        if (cs) atomicAdd(&T.cost_static, cs);
+    }
     for (int i = t; i < kDynWords; i += 256) obuf[i] = 0;
     __syncthreads();
+    const uint32_t nbytes = hi - lo;
+    const uint32_t nstored = nbytes ? (nbytes + 65534u) / 65535u : 1u;     // stored blocks hold <= 65535 bytes
     if (t == 0) {
         static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         int hclen = 19;
         while (hclen > 4 && T.cllen[order[hclen - 1]] == 0) --hclen;
-        uint32_t cur = 0;
-        lds_put(obuf, cur, 0u | (2u << 1), 3);                         // BFINAL = 0, BTYPE = 10 (dynamic)
-        lds_put(obuf, cur, T.hlit - 257, 5);
-        lds_put(obuf, cur, T.hdist - 1, 5);
-        lds_put(obuf, cur, (uint32_t)hclen - 4, 4);
-        for (int i = 0; i < hclen; ++i) lds_put(obuf, cur, T.cllen[order[i]], 3);
+        T.hclen = (uint32_t)hclen;
+        uint32_t hdr = 3 + 5 + 5 + 4 + 3 * (uint32_t)hclen;
         for (uint32_t i = 0; i < T.ncl; ++i) {
-            const uint32_t s = T.clsym[i];
-            lds_put(obuf, cur, T.clcode[s], T.cllen[s]);
-            if (s == 16) lds_put(obuf, cur, T.clext[i], 2);
-            else if (s == 17) lds_put(obuf, cur, T.clext[i], 3);
-            else if (s == 18) lds_put(obuf, cur, T.clext[i], 7);
+            const uint32_t sy = T.clsym[i];
+            hdr += T.cllen[sy] + (sy == 16 ? 2u : (sy == 17 ? 3u : (sy == 18 ? 7u : 0u)));
+        }
+        const uint32_t dyn_lenb = (hdr + T.cost_dyn + 7u) >> 3;
+        const uint32_t static_lenb = (3u + T.cost_static + 7u) >> 3;
+        const uint32_t opt_lenb = static_lenb <= dyn_lenb ? static_lenb : dyn_lenb;
+        const uint32_t stored_lenb = nbytes + 5u * nstored;
+        T.mode = stored_lenb <= opt_lenb ? 2u : (static_lenb <= dyn_lenb ? 1u : 0u);
+    }
+    __syncthreads();
+    const uint32_t mode = T.mode;
+
+    if (mode == 2u) {
+        // stored blocks (RFC 1951 3.2.4): the segment starts on a byte boundary, so this is a byte copy with a
+        // 5-byte header every 65535 bytes
+        uint8_t *outb = job.out;
+        for (uint32_t k = (uint32_t)t; k < nstored; k += 256) {
+            const uint32_t left = nbytes - k * 65535u;
+            const uint32_t ln = left < 65535u ? left : 65535u;
+            uint8_t *h = outb + (size_t)k * 65540u;
+            h[0] = 0;                                                  // BFINAL = 0, BTYPE = 00, padding
+            h[1] = (uint8_t)ln;
+            h[2] = (uint8_t)(ln >> 8);
+            h[3] = (uint8_t)~ln;
+            h[4] = (uint8_t)(~ln >> 8);
+        }
+        for (uint32_t i = (uint32_t)t; i < nbytes; i += 256) outb[i + 5u * (i / 65535u + 1u)] = in[lo + i];
+        if (t == 0) {
+            uint32_t bytes = nbytes + 5u * nstored;
+            if (job.is_last) {                                         // the final empty static block
+                outb[bytes++] = 0x03;
+                outb[bytes++] = 0x00;
+            }
+            seg_len[blockIdx.x] = bytes;
+        }
+        return;
+    }
+    if (mode == 1u) {                                                  // the static code set, RFC 1951 3.2.6
+        for (int sy = t; sy < 288; sy += 256) T.llen[sy] = sy < 144 ? 8 : (sy < 256 ? 9 : (sy < 280 ? 7 : 8));
+        if (t < 32) T.dlen[t] = 5;
+        __syncthreads();
+        huff_codes(T.llen, 288, T.lcode, t);
+        huff_codes(T.dlen, 32, T.dcode, t);
+    }
+
+    // 4. header bits, serial (a few hundred bits)
+    if (t == 0) {
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        const int hclen = (int)T.hclen;
+        uint32_t cur = 0;
+        if (mode == 1u) {
+            lds_put(obuf, cur, 0u | (1u << 1), 3);                     // BFINAL = 0, BTYPE = 01 (static)
+        } else {
+            lds_put(obuf, cur, 0u | (2u << 1), 3);                     // BFINAL = 0, BTYPE = 10 (dynamic)
+            lds_put(obuf, cur, T.hlit - 257, 5);
+            lds_put(obuf, cur, T.hdist - 1, 5);
+            lds_put(obuf, cur, (uint32_t)hclen - 4, 4);
+            for (int i = 0; i < hclen; ++i) lds_put(obuf, cur, T.cllen[order[i]], 3);
+            for (uint32_t i = 0; i < T.ncl; ++i) {
+                const uint32_t sy = T.clsym[i];
+                lds_put(obuf, cur, T.clcode[sy], T.cllen[sy]);
+                if (sy == 16) lds_put(obuf, cur, T.clext[i], 2);
+                else if (sy == 17) lds_put(obuf, cur, T.clext[i], 3);
+                else if (sy == 18) lds_put(obuf, cur, T.clext[i], 7);
+            }
         }
         // flush whole words of the header, keep the partial one as the carry
         const uint32_t full = cur >> 5;
