@@ -50,18 +50,28 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
+def _run_world(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True, True), (1, True, True)]
+    assert sorted(results) == [(r, True, True) for r in range(world)]
+
+
+def test_world_size_2_gloo():
+    _run_world(2)
+
+
+def test_world_size_4_gloo():
+    """the driver's scaling run goes to 8 ranks; 4 here (8 CPUs in this container) covers a rank count at which the
+    stream shards are uneven (7 streams over 4 ranks) and the order-preserving fold has more than one interior rank"""
+    _run_world(4)
 
 
 def test_shard_streams_covers_everything():
