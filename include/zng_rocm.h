@@ -197,10 +197,10 @@ int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs,
 /* ---- whole-stream deflate on device, ONE large stream (chain-walking levels) -----------------
  * The caller this replaces is deflate_medium (deflate_medium.c:145-277) + zng_tr_flush_block's
  * dynamic-tree block (trees.c:625-741) behind DEFLATE_HOOK.  The plaintext is device resident and
- * complete, so it is compressed as parallel 512 KiB segments (hash primed with the preceding 32 KiB,
- * so matches cross segment borders) into one continuous raw RFC 1951 stream: one dynamic-Huffman
- * block per segment, each followed by an empty stored block (byte alignment, as Z_SYNC_FLUSH), and a
- * final empty static block.  `level` 2..9 selects max_chain_length as deflate.c:142-168 does (capped
+ * complete, so it is compressed as parallel 128-512 KiB segments (hash primed with the preceding 32 KiB,
+ * so matches cross segment borders) into one continuous raw RFC 1951 stream: per segment one block whose
+ * type is chosen as zng_tr_flush_block does (stored / static / dynamic, trees.c:660-719), followed by an
+ * empty stored block where byte alignment needs it (as Z_SYNC_FLUSH), and a final empty static block.  `level` 2..9 selects max_chain_length as deflate.c:142-168 does (capped
  * at 256).  d_out needs zng_rocm_deflate_bound(in_len) bytes.  Synchronises `stream` (the segment
  * lengths are prefix-summed on the host).  Returns 0, a ZNG_ROCM_E* code, or -5 (Z_BUF_ERROR). */
 size_t zng_rocm_deflate_bound(size_t source_len);

@@ -92,9 +92,16 @@ def test_block_type_choice(mods):
 
     noise = rng.integers(0, 256, size=(1 << 20) + 777, dtype=np.uint8).tobytes()     # two full segments + a tail
     comp = run(noise)
-    nblocks = sum((n + 65534) // 65535 for n in (512 << 10, 512 << 10, 777))
-    assert len(comp) == len(noise) + 5 * nblocks + 2                    # + the final empty static block
-    assert (comp[0] >> 1) & 3 == 0 and comp[1:3] == (65535).to_bytes(2, "little")
+    pos = payload = nblocks = 0                                         # nothing but stored blocks ...
+    while pos < len(comp) - 2:
+        ln = int.from_bytes(comp[pos + 1:pos + 3], "little")
+        assert comp[pos] == 0 and int.from_bytes(comp[pos + 3:pos + 5], "little") == ln ^ 0xffff
+        pos += 5 + ln
+        payload += ln
+        nblocks += 1
+    assert payload == len(noise) and comp[pos:] == b"\x03\x00"           # ... and the final empty static block
+    assert nblocks <= len(noise) // 65535 + 2 * (len(noise) // (128 << 10) + 1)   # segments are >= 128 KiB
+    assert comp[1:3] == (65535).to_bytes(2, "little")
     for data in (b"", b"q", b"abcabcabcabc"):
         comp = run(data)
         assert (comp[0] >> 1) & 3 == 1, data                              # static

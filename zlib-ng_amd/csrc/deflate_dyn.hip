@@ -38,7 +38,16 @@ struct SegJob {
     uint64_t       sel_off;   // selector index of stream position 0
 };
 
-constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block
+constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block: the largest, and ...
+constexpr uint32_t kSegBytesMin = 128u << 10;  // ... the smallest.  A segment is one workgroup and one CU holds one
+                                               // workgroup, so a stream is cut into at least ~2 segments per CU when
+                                               // it is long enough (each segment re-inserts the 32 KiB before it:
+                                               // 6 % extra work at 512 KiB, 25 % at 128 KiB)
+static uint32_t segment_bytes(size_t in_len, int cus) {
+    uint32_t seg = kSegBytes;
+    while (seg > kSegBytesMin && in_len / seg < 2u * (size_t)cus) seg >>= 1;
+    return seg;
+}
 constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
 
 // grid.x = segment.  The plaintext streams through the LDS ring one batch ahead of the parse: 256 lanes fetch the
@@ -586,7 +595,7 @@ using namespace zr;
 extern "C" {
 
 size_t zng_rocm_deflate_bound(size_t source_len) {
-    const size_t nseg = source_len ? (source_len + kSegBytes - 1) / kSegBytes : 1;
+    const size_t nseg = source_len ? (source_len + kSegBytesMin - 1) / kSegBytesMin : 1;     // the most there can be
     return source_len + source_len / 8 + nseg * 1032 + 16;
 }
 
@@ -618,12 +627,15 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};     // good_match per level, deflate.c:142-168
     const uint32_t good_match = goods[level];
 
-    const size_t nseg = in_len ? (in_len + kSegBytes - 1) / kSegBytes : 1;
+    int32_t dev_info[4] = {256, 0, 64, 8};
+    (void)zng_rocm_device_info(dev_info);
+    const size_t seg_bytes = segment_bytes(in_len, dev_info[0]);
+    const size_t nseg = in_len ? (in_len + seg_bytes - 1) / seg_bytes : 1;
     std::vector<SegJob> jobs(nseg);
     size_t slot_total = 0;
     for (size_t i = 0; i < nseg; ++i) {
-        const uint32_t a = (uint32_t)(i * kSegBytes);
-        const uint32_t b = (uint32_t)((i + 1) * kSegBytes < in_len ? (i + 1) * kSegBytes : in_len);
+        const uint32_t a = (uint32_t)(i * seg_bytes);
+        const uint32_t b = (uint32_t)((i + 1) * seg_bytes < in_len ? (i + 1) * seg_bytes : in_len);
         jobs[i].in = d_in;
         jobs[i].seg_start = a;
         jobs[i].seg_end = b;
