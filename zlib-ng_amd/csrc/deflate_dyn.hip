@@ -167,11 +167,10 @@ __device__ void huff_lengths(DynTables *T, uint32_t *freq, int n, int maxbits, u
             }
         }
         __syncthreads();
-        __shared__ int m_used, too_deep;
+        __shared__ int too_deep;
         if (t == 0) {
             int m = 0;
             for (int i = 0; i < n; ++i) m += freq[i] != 0;
-            m_used = m;
             // two-queue merge: leaves ascending in w[0..m), internal nodes appended at w[288..]
             int li = 0, ii = 0, ni = 0;                       // next leaf, next internal, internal count
             for (int k = 0; k + 1 < m; ++k) {
