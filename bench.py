@@ -153,7 +153,7 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse):
                                    "sharded %d-way, {clen, adler32, ulen} table all-gathered" % (args.streams, world),
                        "streams_per_gpu": count, "ratio": round(total_in / total_out, 3),
                        "parallelism": "streams/%d+allgather(24B/stream)" % world, "rehearsal_same_gpu": rehearse},
-            "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (latency bound: serial-per-stream LZ77 front end)",
+            "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (scalar-issue and barrier bound LZ77 front end, see DESIGN.md 3.4)",
                          "achieved": round(local_bytes / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
