@@ -36,6 +36,13 @@ namespace zr {
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // streaming (read-once) 16-byte load: non-temporal hint, the data is never re-read
+// streaming store of one piece: written once, never read back by this kernel
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(uint8_t *p, uint4 v) {
+    u32x4_nt x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4_nt *>(p));
+}
+
 __device__ __forceinline__ uint4 ld_stream(const uint8_t *p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -199,7 +206,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             if constexpr (COPY) {
 #pragma unroll
                 for (int j = 0; j < UNROLL; ++j)
-                    *reinterpret_cast<uint4 *>(args.dst0 + off + (long long)j * kUnitBytes) = buf[j];
+                    st_stream(args.dst0 + off + (long long)j * kUnitBytes, buf[j]);
             }
 #pragma unroll
             for (int j = 0; j < UNROLL; ++j) consume(buf[j]);

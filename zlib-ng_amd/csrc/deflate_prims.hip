@@ -254,7 +254,7 @@ void chunkmemset_kernel(uint8_t *__restrict__ base, const uint64_t *__restrict__
         uint8_t tb = 0;
         if (l < ntail) tb = load_u8(from + (pattern ? p % period : p));
         __builtin_amdgcn_s_waitcnt(0);                               // every load of the round has landed
-        if (l < full) *(ZR_GLOBAL u32x4_unaligned *)(out + i) = v;
+        if (l < full) __builtin_nontemporal_store(v, (ZR_GLOBAL u32x4_unaligned *)(out + i));   // written once, streamed
         if (l < ntail) *(ZR_GLOBAL uint8_t *)(out + p) = tb;
         round += span;
         live = live && round < len;

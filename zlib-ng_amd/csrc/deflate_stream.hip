@@ -66,7 +66,7 @@ void lz_parse_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict
             uint32_t s = 0;
             if (r.kind == 2u) s = 0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u);
             else if (r.kind == 1u) s = 0x40000000u;
-            sel[p] = s;
+            __builtin_nontemporal_store(s, sel + p);        // read once, by the emitter, long after
         }
         val = val_next;
     }
@@ -207,7 +207,7 @@ void emit_static_kernel(const StreamJobDev *__restrict__ jobs, const uint32_t *_
         __syncthreads();
         const uint32_t total = cbits + tile_bits;
         const uint32_t full = total >> 5;
-        for (uint32_t i = (uint32_t)t; i < full; i += 256) outw[wbase + i] = obuf[i];
+        for (uint32_t i = (uint32_t)t; i < full; i += 256) __builtin_nontemporal_store(obuf[i], outw + wbase + i);
         const uint32_t next_cw = obuf[full];
         __syncthreads();
         wbase += full;

@@ -202,7 +202,7 @@ void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, c
                 if (v >= 256) v = base_prev[v - 256];
             }
         }
-        out[i] = (uint8_t)v;
+        __builtin_nontemporal_store((uint8_t)v, out + i);
     }
 }
 
