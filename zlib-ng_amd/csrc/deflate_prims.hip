@@ -205,6 +205,8 @@ void longest_match_slow_kernel(const zng_rocm_deflate_view *__restrict__ views, 
 // is one dwordx4 and one byte access each way per lane; a lane whose sixteen bytes are not one contiguous run of
 // the source (the pattern wraps inside them) gathers them bytewise.  Nothing outside [out, out+len) is written
 // and nothing outside [from, from+len) is read.
+// The vector stores are non-temporal (the outputs are written once and not read back: 0.50 -> 0.63 of peak at len
+// 256, 0.65 -> 0.77 at len 4096); non-temporal LOADS of the sources lose (0.63 -> 0.55, 0.77 -> 0.51).
 // Measured and rejected: 2 or 4 copies in flight per 16-lane group (slower: 0.59 -> 0.53 / 0.45 of peak at len
 // 256), and a byte head that aligns the dwordx4 stores (no gain; the extra byte access costs more).
 typedef uint32_t u32x4_plain __attribute__((ext_vector_type(4)));
