@@ -477,10 +477,26 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
         const uint32_t p0 = base + (uint32_t)t * kDynPer;
         uint32_t c1[kDynPer], n1[kDynPer], c2[kDynPer], n2[kDynPer];
         uint32_t mine = 0;
+        // this lane's 16 input bytes in one (unaligned) dwordx4 instead of up to 16 byte loads; bytes beyond the end of
+        // the stream are never looked at (p < hi below), the slack after the last segment is the caller's 16 bytes
+        uint32_t rw[4] = {0u, 0u, 0u, 0u};
+        if (p0 + 16u <= hi) {
+            const u32x4_unaligned raw = load_u128(in + p0);
+            rw[0] = raw.x; rw[1] = raw.y; rw[2] = raw.z; rw[3] = raw.w;
+        } else {
+            for (uint32_t q = p0; q < hi; ++q) rw[(q - p0) >> 2] |= (uint32_t)in[q] << (8u * ((q - p0) & 3u));
+        }
+        uint32_t sv[kDynPer];                            // 16 selectors as four dwordx4 loads (segments start 16-aligned)
+#pragma unroll
+        for (int q = 0; q < kDynPer / 4; ++q) {
+            uint4 v4 = make_uint4(0, 0, 0, 0);
+            if (p0 < hi) v4 = reinterpret_cast<const uint4 *>(sel + p0)[q];
+            sv[4 * q] = v4.x; sv[4 * q + 1] = v4.y; sv[4 * q + 2] = v4.z; sv[4 * q + 3] = v4.w;
+        }
 #pragma unroll
         for (int j = 0; j < kDynPer; ++j) {
             const uint32_t p = p0 + (uint32_t)j;
-            const uint32_t s = p < hi ? sel[p] : 0u;
+            const uint32_t s = p < hi ? sv[j] : 0u;
             c1[j] = n1[j] = c2[j] = n2[j] = 0;
             if (s & 0x80000000u) {
                 uint32_t sym, eb, ev;
@@ -491,7 +507,7 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
                 c2[j] = (uint32_t)T.dcode[sym] | (ev << T.dlen[sym]);
                 n2[j] = T.dlen[sym] + eb;
             } else if (s & 0x40000000u) {
-                const uint32_t b = in[p];
+                const uint32_t b = (rw[j >> 2] >> (8 * (j & 3))) & 0xffu;
                 c1[j] = T.lcode[b];
                 n1[j] = T.llen[b];
             }

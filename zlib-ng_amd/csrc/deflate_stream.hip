@@ -167,10 +167,19 @@ void emit_static_kernel(const StreamJobDev *__restrict__ jobs, const uint32_t *_
             accA += a;
         }
         const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+        // this lane's 16 selectors as four dwordx4 loads (the stream's selector region is 16-byte aligned and the
+        // workspace is padded): 16 single loads would each make the wave touch 64 different cache lines
+        uint32_t sv[kEmitPer];
+#pragma unroll
+        for (int q = 0; q < kEmitPer / 4; ++q) {
+            uint4 v4 = make_uint4(0, 0, 0, 0);
+            if (p0 < n) v4 = reinterpret_cast<const uint4 *>(sel + p0)[q];
+            sv[4 * q] = v4.x; sv[4 * q + 1] = v4.y; sv[4 * q + 2] = v4.z; sv[4 * q + 3] = v4.w;
+        }
 #pragma unroll
         for (int j = 0; j < kEmitPer; ++j) {
             const uint32_t p = p0 + (uint32_t)j;
-            uint32_t s = p < n ? sel[p] : 0u;
+            uint32_t s = p < n ? sv[j] : 0u;
             code[j] = 0;
             nbv[j] = 0;
             if (s & 0x80000000u) static_match(((s >> 16) & 0xffu) + 3u, (s & 0xffffu) + 1u, code[j], nbv[j]);
@@ -294,7 +303,7 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
             return ZNG_ROCM_EINVAL;
         }
         g_ds.h_jobs[i] = StreamJobDev{j.in, j.out, j.in_len, j.out_cap, total};
-        total += j.in_len;
+        total += ((uint64_t)j.in_len + 3u) & ~3ull;           // selector regions stay 16-byte aligned
     }
     if (total > g_ds.sel_cap) {
         if (g_ds.d_sel) (void)hipFree(g_ds.d_sel);
