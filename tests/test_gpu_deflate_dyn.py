@@ -113,3 +113,36 @@ def test_block_type_choice(mods):
     mixed = noise[:512 << 10] + (text * 4)[:512 << 10] + noise[:300000]
     comp = run(mixed)
     assert len(comp) < len(mixed) - 400000
+
+
+def test_three_gib_stream(mods):
+    """32-bit positions: one stream of 3 GiB + 12345 bytes (6145 segments) round-trips; 4 GiB is refused.  The check
+    is size-independent: CRC-32 and length of what CPython's zlib inflates == the device CRC-32 of the source."""
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    block = torch.from_numpy(synth.silesia_like(64 << 20, seed=0x5EED0033, seg_bytes=4 << 20)).cuda()
+    n = (3 << 30) + 12345
+    src = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+    for lo in range(0, n + 16, block.numel()):
+        hi = min(n + 16, lo + block.numel())
+        src[lo:hi] = block[:hi - lo]
+    src[1 << 31] ^= 0x5a                                    # the copies are not all identical
+    dst, clen = dfl.deflate_dev(src, level=4, length=n)
+    out2 = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zr.crc32_dev(src, out2, length=n)
+    want_crc = out2[0].item() & 0xffffffff
+    comp = dst[:clen].cpu().numpy()
+    d = zlib.decompressobj(-15)
+    crc, total, pos = 0, 0, 0
+    while pos < comp.size:                                  # streamed: never holds the 3 GiB at once
+        piece = d.decompress(comp[pos:pos + (8 << 20)].tobytes())
+        crc = zlib.crc32(piece, crc)
+        total += len(piece)
+        pos += 8 << 20
+    tail = d.flush()
+    crc = zlib.crc32(tail, crc)
+    total += len(tail)
+    assert d.eof and total == n and crc == want_crc
+    assert clen < n // 2
+    with pytest.raises(Exception):
+        dfl.deflate_dev(src, level=4, length=(1 << 32) - (64 << 10))      # beyond the 32-bit position format
