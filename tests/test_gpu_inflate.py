@@ -124,3 +124,32 @@ def test_cfg3_scale_stream(inf):
     out = torch.zeros(2, dtype=torch.int32, device="cuda")
     zr.adler32_crc32_dev(got, out)
     assert [v & 0xffffffff for v in out.tolist()] == [zlib.adler32(plain.tobytes()), zlib.crc32(plain.tobytes())]
+
+
+def test_output_beyond_4gib(inf):
+    """64-bit output positions: a stream that inflates to 4.5 GiB + 321 bytes (about 140 k segments, 2200 groups of
+    the context chain).  Size-independent check: device CRC-32 + Adler-32 of the plaintext on the device against the
+    same checksums accumulated on the host while the stream is built."""
+    torch = torch_mod()
+    zr = product()
+    rng = np.random.default_rng(91)
+    piece = bytes(rng.integers(0, 4, size=64 << 10, dtype=np.uint8)) + b"\0" * ((4 << 20) - (64 << 10))   # 4 MiB
+    n_pieces, tail = 1152, b"tail" * 80 + b"!"
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    comp, crc, adler = [], 0, 1
+    for _ in range(n_pieces):
+        comp.append(c.compress(piece))
+        crc, adler = zlib.crc32(piece, crc), zlib.adler32(piece, adler)
+    comp.append(c.compress(tail))
+    comp.append(c.flush())
+    crc, adler = zlib.crc32(tail, crc), zlib.adler32(tail, adler)
+    comp = b"".join(comp)
+    total = n_pieces * len(piece) + len(tail)
+    assert total > (1 << 32)
+    dec = inf.decode_tokens(comp)
+    assert dec.status == 1 and dec.out_len == total and dec.in_used == len(comp)
+    out = inf.resolve_dev(dec)
+    chk = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zr.adler32_crc32_dev(out, chk, adler=1, crc=0, length=total)
+    assert [v & 0xffffffff for v in chk.tolist()] == [adler, crc]
+    assert out[-len(tail):].cpu().numpy().tobytes() == tail
