@@ -93,3 +93,32 @@ def test_many_equal_streams_and_rerun(mods):
     raw = data.tobytes()
     for i in range(n):
         assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == raw[i * each:(i + 1) * each]
+
+
+def test_many_tiny_streams_and_one_long(mods):
+    """batch shapes at the edges: 20000 streams of 0..200 bytes in one launch, and one stream of 40 MiB + 3
+    (positions beyond 2^24, the level-1 class kernel's whole 32-bit range is the contract)"""
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    rng = np.random.default_rng(23)
+    tiny = [bytes(rng.integers(97, 101, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 201, size=20000)]
+    blob, offs, lens = _pack(tiny)
+    batch = dfl.QuickBatch(torch.from_numpy(blob).cuda(), offs, lens)
+    batch.run()
+    torch.cuda.synchronize()
+    res = batch.results.cpu().numpy()
+    dst = batch.dst.cpu().numpy()
+    for i in range(0, len(tiny), 37):
+        comp = dst[batch.out_off[i]:batch.out_off[i] + int(res[i, 0])].tobytes()
+        d = zlib.decompressobj(-15)
+        assert d.decompress(comp) == tiny[i] and d.eof, i
+        assert (int(res[i, 1]) & 0xffffffff) == zlib.adler32(tiny[i]), i
+    long = synth.silesia_like((40 << 20) + 3, seed=5, seg_bytes=1 << 20)
+    blob, offs, lens = _pack([long.tobytes()])
+    batch = dfl.QuickBatch(torch.from_numpy(blob).cuda(), offs, lens)
+    batch.run()
+    torch.cuda.synchronize()
+    comp = batch.compressed(0)
+    d = zlib.decompressobj(-15)
+    assert d.decompress(comp) == long.tobytes() and d.eof
+    assert (int(batch.results.cpu()[0, 1]) & 0xffffffff) == zlib.adler32(long.tobytes())
