@@ -196,12 +196,19 @@ def main():
     # ZNG_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- lets the N>1 control flow be
     # rehearsed on a one-GPU box (RCCL refuses two ranks on one device); numbers from it mean nothing.
     rehearse = os.environ.get("ZNG_BENCH_REHEARSE") == "1"
+    # ZNG_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL all-gather on the side stream, combine_rows) with a
+    # one-rank process group -- the way to exercise that path on a one-GPU box
+    force_dist = os.environ.get("ZNG_BENCH_FORCE_DIST") == "1" and world == 1
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
@@ -223,21 +230,61 @@ def main():
     gen.manual_seed(SEED + rank)
     buf = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=gen)
     out = torch.zeros(2, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(world * 4, dtype=torch.int64, device=dev)
-    mine = torch.zeros(4, dtype=torch.int64, device=dev)
-    total = torch.zeros(2, dtype=torch.int32, device=dev)
+    # N > 1: each rank's {adler, crc, len} row (16 bytes, zng_rocm_check_row) is all-gathered and folded in rank order
+    # by ONE device launch pair (zng_rocm_combine_rows_dev).  The exchange of step k runs on a side stream while the
+    # main stream is already in step k+1's checksum kernel: the collective (latency bound: 16 bytes per rank over
+    # xGMI) never sits on the critical path.  Rows rotate through k_slots buffers; a slot is reused only after the
+    # side stream has released it.  The checksum kernel writes its two words straight into the row.
+    multi = world > 1 or force_dist
+    k_slots = 8
+    rows_local = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(k_slots)]
+    for r in rows_local:
+        lo = n & 0xffffffff
+        r[2] = lo if lo < (1 << 31) else lo - (1 << 32)
+        r[3] = n >> 32
+    rows_all = [torch.zeros(world * 4, dtype=torch.int32, device=dev) for _ in range(k_slots)]
+    totals = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(k_slots)]
+    side = torch.cuda.Stream(device=dev, priority=-1)    # its own hardware queue: must not share the main one
+    produced = [torch.cuda.Event() for _ in range(k_slots)]
+    released = [torch.cuda.Event() for _ in range(k_slots)]
+    state = {"k": 0}
+
+    # Host cost matters as much as device cost here: a step is 0.18 ms of kernel, and every Python-side stream switch
+    # or tensor op in the loop is tens of microseconds.  So inside the loop torch's *current* stream IS the exchange
+    # stream (the collective and the combine pick it up implicitly) and the checksum kernel is launched on `main`
+    # explicitly -- no per-step stream context, no tensor arithmetic.
+    main = torch.cuda.current_stream()
+    if multi and not rehearse:
+        torch.cuda.set_stream(side)
+        # the checksum grid is one workgroup per CU for the whole pass: leave a few CUs to the exchange stream, or its
+        # kernels displace a workgroup the pass then waits for (measured on one GPU with a one-rank RCCL group:
+        # 0.225 ms per step with every CU taken)
+        zr.reserve_cus(int(os.environ.get("ZNG_BENCH_RESERVE_CUS", "8")))
 
     def step():
-        zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
-        if world > 1:
-            # exchange: {adler, crc, len} per rank, then the ordered combine on device
-            mine[0:2] = out.to(torch.int64) & 0xffffffff
-            mine[2] = n
-            # same code path the world_size-2 gloo test covers (32 bytes per rank over RCCL)
-            g = par.gather_rows(mine.cpu()).to(dev) if rehearse else par.gather_rows(mine)
-            lens = g[:, 2].contiguous()
-            zr.adler32_combine_dev(g[:, 0].to(torch.int32).contiguous(), lens, total[0:1])
-            zr.crc32_combine_dev(g[:, 1].to(torch.int32).contiguous(), lens, total[1:2])
+        if not multi:
+            zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
+            return
+        slot = state["k"] % k_slots
+        state["k"] += 1
+        row = rows_local[slot]
+        if slot == 0 and state["k"] > k_slots:
+            # once per round of slots: the exchange stream has finished with the previous round (its last release is
+            # the youngest), so every slot may be written again.  A wait per step would put a barrier packet in front
+            # of every checksum launch (measured: ~8 us each).
+            main.wait_event(released[k_slots - 1])
+        zr.adler32_crc32_dev(buf, row, adler=1, crc=0, stream=main)       # row[0:2] <- {adler, crc}
+        if rehearse:
+            # gloo has no device tensors: same payload and fold, synchronously through the host
+            g = par.gather_check_rows(row.cpu()).to(dev)
+            zr.combine_rows_dev(g, world, totals[slot], stream=main)
+            released[slot].record(main)
+            return
+        produced[slot].record(main)
+        side.wait_event(produced[slot])
+        par.gather_check_rows(row, rows_all[slot])       # RCCL all-gather on the current (= exchange) stream, 16 B per rank
+        zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=side)
+        released[slot].record(side)
 
     def fence():
         if world > 1:
@@ -261,13 +308,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
-    result = [v & 0xffffffff for v in out.tolist()]
-    if world > 1:
+    torch.cuda.set_stream(main)
+    last = (state["k"] - 1) % k_slots if multi else 0
+    result = [v & 0xffffffff for v in (rows_local[last][0:2] if multi else out).tolist()]
+    if multi:
         # the on-device ordered combine must equal the host fold of the gathered rows
-        rows = (par.gather_rows(mine.cpu()) if rehearse else par.gather_rows(mine)).cpu()[:, :3].tolist()
+        mine = rows_local[last]
+        g = par.gather_check_rows(mine.cpu()) if rehearse else par.gather_check_rows(mine)
+        rows = par.check_rows_to_list(g.cpu())
         folded = par.fold_checksums(rows)
-        got_total = [v & 0xffffffff for v in total.tolist()]
+        got_total = [v & 0xffffffff for v in totals[last].tolist()]
         assert got_total == [folded[0], folded[1]], (got_total, folded)
+        assert rows[rank][:2] == result and all(r[2] == n for r in rows)
     # separate single-checksum timings (outside the timed region, informational)
     extra = {}
     for name, fn in (("adler32", lambda: zr.adler32_dev(buf, out)), ("crc32", lambda: zr.crc32_dev(buf, out))):
@@ -302,7 +354,8 @@ def main():
                 "workload": "configs[1]: crc32 + adler32 over a %d MiB synthetic buffer per GPU, HBM-resident, "
                             "fused single pass + on-device combine" % (n >> 20),
                 "bytes_per_gpu": n,
-                "parallelism": "shard%d+allgather(32B/rank)+ordered-combine" % world if world > 1 else "single",
+                "parallelism": ("shard%d+allgather(16B/rank, side stream, overlapped with the next step)+ordered-combine" % world)
+                if multi else "single",
                 "checksums": ["%08x" % result[0], "%08x" % result[1]],
                 "rehearsal_same_gpu": rehearse,
             },
@@ -328,7 +381,7 @@ def main():
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

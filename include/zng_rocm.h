@@ -54,6 +54,11 @@ const char *zng_rocm_last_error(void);
 /* {CUs, LDS bytes per CU, wavefront size, XCDs} of the initialised device */
 int         zng_rocm_device_info(int32_t out[4]);
 int         zng_rocm_shutdown(void);
+/* The checksum kernels run one workgroup per CU for the whole pass.  A caller that overlaps them with work on
+ * other HIP streams of the same device (an RCCL collective, the combine of the previous step) asks for `n` CUs
+ * to be left out of that grid, so the other stream's kernels do not have to displace a workgroup the whole pass
+ * waits for.  0 (the default) = use every CU.  Process-wide; takes effect at the next launch. */
+int         zng_rocm_reserve_cus(int n);
 
 /* ---- functable slots, host pointers (functable.h:26-42) ---------------- */
 /* slot `adler32`: arch/generic/adler32_c.c:11-54 */
@@ -98,6 +103,15 @@ int zng_rocm_adler32_combine_dev(const uint32_t *d_checks, const uint64_t *d_len
                                  uint32_t *d_out, void *stream);
 int zng_rocm_crc32_combine_dev(const uint32_t *d_checks, const uint64_t *d_lens, size_t count,
                                uint32_t *d_out, void *stream);
+
+/* The same fold over packed rows {adler32, crc32, len} -- the payload the multi-GPU aggregate all-gathers
+ * (one 16-byte row per rank or shard): d_out2[0] = adler32, d_out2[1] = crc32 of the
+ * concatenation, rows in order.  Asynchronous on `stream`, no allocation: made to be chained behind a collective. */
+typedef struct zng_rocm_check_row {
+    uint32_t adler, crc;
+    uint64_t len;
+} zng_rocm_check_row;
+int zng_rocm_combine_rows_dev(const zng_rocm_check_row *d_rows, size_t count, uint32_t *d_out2, void *stream);
 
 /* host-side scalar forms with the reference's exact semantics
  * (zng_adler32_combine adler32.c:66-68; zng_crc32_combine/_gen/_op

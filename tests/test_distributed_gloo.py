@@ -35,6 +35,18 @@ def _worker(rank, world, port, q):
         mine = whole[cuts[rank]:cuts[rank + 1]]
         got = par.aggregate_checksums(zlib.adler32(mine), zlib.crc32(mine), len(mine))
         ok1 = got == (zlib.adler32(whole), zlib.crc32(whole), len(whole))
+        # the packed 16-byte row form bench.py sends ({u32 adler, u32 crc, u64 len} as int32[4]); a length above 2^32
+        # exercises both halves of the u64
+        big = (5 << 30) + rank
+        a, c = zlib.adler32(mine), zlib.crc32(mine)
+        row = torch.tensor([a - (1 << 32) if a >> 31 else a, c - (1 << 32) if c >> 31 else c,
+                            (big & 0xffffffff) - (1 << 32) if (big >> 31) & 1 else big & 0xffffffff, big >> 32],
+                           dtype=torch.int32)
+        rows = par.check_rows_to_list(par.gather_check_rows(row))
+        ok1 = ok1 and rows[rank] == [a, c, big] and [r[2] for r in rows] == [(5 << 30) + k for k in range(world)]
+        rows_true = par.check_rows_to_list(par.gather_check_rows(torch.tensor(
+            [row[0].item(), row[1].item(), len(mine), 0], dtype=torch.int32)))
+        ok1 = ok1 and par.fold_checksums(rows_true) == (zlib.adler32(whole), zlib.crc32(whole), len(whole))
         # --- multi-stream table
         nstreams = 7
         first, count = par.shard_streams(nstreams, world, rank)

@@ -250,3 +250,39 @@ def test_beyond_4gib(zr, oracle):
     assert got[1] == oracle.oracle_crc32(0, host.ctypes.data, n)
     # host-pointer slot with a > 4 GiB buffer (PCIe staging inside)
     assert zr.crc32_z(0, host) == got[1]
+
+
+def test_combine_rows_dev(zr, oracle):
+    """zng_rocm_combine_rows_dev: packed {adler, crc, len} rows (the multi-GPU aggregate's payload) folded in order
+    on the device == the oracle's left fold with adler32_combine / crc32_combine; lengths above 2^32 included."""
+    torch = torch_mod()
+    rng = np.random.default_rng(31)
+    for count in (1, 2, 3, 8, 64, 1000, 1025, 3000):
+        rows = np.zeros(count, dtype=[("adler", "<u4"), ("crc", "<u4"), ("len", "<u8")])
+        pieces = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(count)]
+        for i, pbytes in enumerate(pieces):
+            arr = np.frombuffer(pbytes, dtype=np.uint8)
+            rows["adler"][i] = oracle.oracle_adler32(1, arr.ctypes.data if arr.size else None, arr.size)
+            rows["crc"][i] = oracle.oracle_crc32(0, arr.ctypes.data if arr.size else None, arr.size)
+            rows["len"][i] = arr.size
+        whole = np.frombuffer(b"".join(pieces) + b"\0", dtype=np.uint8)
+        n = whole.size - 1
+        want = [oracle.oracle_adler32(1, whole.ctypes.data, n), oracle.oracle_crc32(0, whole.ctypes.data, n)]
+        d_rows = torch.from_numpy(rows.view(np.int32).copy()).cuda()
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        zr.combine_rows_dev(d_rows, count, out)
+        assert [v & 0xffffffff for v in out.tolist()] == want, count
+    # lengths beyond 2^32: against the oracle's scalar combine
+    rows = np.zeros(3, dtype=[("adler", "<u4"), ("crc", "<u4"), ("len", "<u8")])
+    rows["adler"] = [0x12345678 % 0xfff1fff1, 0x0badf00d, 0x00010001]
+    rows["adler"][0] = (0x1234 << 16) | 0x0567
+    rows["adler"][1] = (0xfff0 << 16) | 0xfff0
+    rows["crc"] = [0xdeadbeef, 0x01234567, 0xffffffff]
+    rows["len"] = [(1 << 33) + 5, 7, (3 << 32) + 11]
+    a, c = 1, 0
+    for r in rows:
+        a = oracle.oracle_adler32_combine(a, int(r["adler"]), int(r["len"]))
+        c = oracle.oracle_crc32_combine(c, int(r["crc"]), int(r["len"]))
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    zr.combine_rows_dev(torch.from_numpy(rows.view(np.int32).copy()).cuda(), 3, out)
+    assert [v & 0xffffffff for v in out.tolist()] == [a, c]

@@ -19,5 +19,5 @@ from .rocm import (  # noqa: F401
     adler32, crc32, adler32_z, crc32_z, adler32_fold_copy,
     adler32_combine, crc32_combine, crc32_combine_gen, crc32_combine_op,
     adler32_dev, crc32_dev, adler32_crc32_dev, fold_copy_dev,
-    adler32_combine_dev, crc32_combine_dev, Crc32Fold, trace_begin, trace_end,
+    adler32_combine_dev, crc32_combine_dev, combine_rows_dev, reserve_cus, Crc32Fold, trace_begin, trace_end,
 )

@@ -31,6 +31,8 @@
 // dependent device-scope atomics cost ~6 us per call, more than the 3-4 us of the second launch.)
 #include "context.h"
 
+#include <atomic>
+
 namespace zr {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -391,8 +393,14 @@ void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const 
 }
 
 // ---- host launcher ----------------------------------------------------------
+// CUs the persistent checksum grid leaves alone (zng_rocm_reserve_cus): a workgroup of this kernel fills its CU, so
+// a kernel of another stream -- an RCCL collective, a combine -- that lands on one of them stalls that CU's whole
+// share of the pass, and with it the pass.  With a few CUs left free the other stream has somewhere to go.
+static std::atomic<int> g_reserved_cus{0};
+
 static int pick_groups(const Context *c, long long nunits) {
-    long long g = c->cus;                 // one 1024-thread workgroup per CU
+    long long g = c->cus - g_reserved_cus.load(std::memory_order_relaxed);   // one 1024-thread workgroup per CU
+    if (g < 1) g = 1;
     if (g > kMaxGroups) g = kMaxGroups;
     if (nunits < g) g = nunits > 0 ? nunits : 1;
     return (int)g;
@@ -501,6 +509,17 @@ int zng_rocm_fold_copy_dev(int which, uint32_t adler, uint32_t crc, void *d_dst,
     if (len == 0) d_dst = nullptr;
     return launch_checksum((which & 1) != 0, (which & 2) != 0, adler, crc, d_src, d_dst, len, d_out2, d_out2 + 1,
                            (hipStream_t)stream);
+}
+
+int zng_rocm_reserve_cus(int n) {
+    Context *c = ctx();
+    if (!c) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (n < 0 || n >= c->cus) return ZNG_ROCM_EINVAL;
+    g_reserved_cus.store(n, std::memory_order_relaxed);
+    return ZNG_ROCM_OK;
 }
 
 }  // extern "C"

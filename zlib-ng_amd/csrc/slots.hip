@@ -69,6 +69,7 @@ static void run_host(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, c
 template <bool IS_CRC>
 __global__ __launch_bounds__(1024)
 void combine_kernel(const uint32_t *__restrict__ checks, const uint64_t *__restrict__ lens, long long count,
+                    long long check_stride, long long len_stride,      // in elements: 1, 1 for plain arrays
                     const DeviceTables *__restrict__ tabs, uint32_t *__restrict__ out) {
     __shared__ unsigned long long scan[1024];
     __shared__ unsigned long long red_a[16], red_b[16];
@@ -85,7 +86,7 @@ void combine_kernel(const uint32_t *__restrict__ checks, const uint64_t *__restr
         const int m = (int)(hi - lo);
         // reversed order inside the tile: slot j holds block hi-1-j, inclusive prefix = suffix sum
         const long long idx = hi - 1 - t;
-        unsigned long long len = (t < m) ? lens[idx] : 0;
+        unsigned long long len = (t < m) ? lens[idx * len_stride] : 0;
         scan[t] = len;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -97,7 +98,7 @@ void combine_kernel(const uint32_t *__restrict__ checks, const uint64_t *__restr
         const unsigned long long base = carry;
         const unsigned long long after = base + scan[t] - len;
         if (t < m) {
-            uint32_t chk = checks[idx];
+            uint32_t chk = checks[idx * check_stride];
             if (IS_CRC) {
                 c ^= mulmod(chk, xpow_bytes(tabs->pow_tab, after));
             } else {
@@ -146,7 +147,7 @@ void combine_kernel(const uint32_t *__restrict__ checks, const uint64_t *__restr
 
 template <bool IS_CRC>
 static int launch_combine(const uint32_t *d_checks, const uint64_t *d_lens, size_t count, uint32_t *d_out,
-                          hipStream_t stream) {
+                          hipStream_t stream, long long check_stride = 1, long long len_stride = 1) {
     Context *c = ctx();
     if (!c) {
         set_error("zng_rocm_init() has not succeeded");
@@ -154,7 +155,7 @@ static int launch_combine(const uint32_t *d_checks, const uint64_t *d_lens, size
     }
     if (!d_out || (count && (!d_checks || !d_lens))) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL((combine_kernel<IS_CRC>), dim3(1), dim3(1024), 0, stream, d_checks, d_lens, (long long)count,
-                       c->tables, d_out);
+                       check_stride, len_stride, c->tables, d_out);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }
@@ -232,6 +233,15 @@ int zng_rocm_adler32_combine_dev(const uint32_t *d_checks, const uint64_t *d_len
 int zng_rocm_crc32_combine_dev(const uint32_t *d_checks, const uint64_t *d_lens, size_t count, uint32_t *d_out,
                                void *stream) {
     return launch_combine<true>(d_checks, d_lens, count, d_out, (hipStream_t)stream);
+}
+
+int zng_rocm_combine_rows_dev(const zng_rocm_check_row *d_rows, size_t count, uint32_t *d_out2, void *stream) {
+    if (!d_out2 || (count && !d_rows)) return ZNG_ROCM_EINVAL;
+    static_assert(sizeof(zng_rocm_check_row) == 16, "row layout is part of the ABI");
+    const uint32_t *first = reinterpret_cast<const uint32_t *>(d_rows);
+    const uint64_t *lens = reinterpret_cast<const uint64_t *>(d_rows) + 1;
+    if (int rc = launch_combine<false>(first, lens, count, d_out2, (hipStream_t)stream, 4, 2)) return rc;
+    return launch_combine<true>(first + 1, lens, count, d_out2 + 1, (hipStream_t)stream, 4, 2);
 }
 
 uint32_t zng_rocm_adler32_combine(uint32_t adler1, uint32_t adler2, int64_t len2) {

@@ -2,7 +2,7 @@
 "gloo" in CPU tests).  The hot path shards two ways and neither moves bulk data:
 
   * one big checksum: rank r owns the r-th contiguous range; the ONLY exchange is an all-gather of
-    {adler, crc, len} (24 bytes per rank) followed by the ordered combine (adler32_combine / crc32_combine
+    {adler, crc, len} (16 bytes per rank, zng_rocm_check_row) followed by the ordered combine (adler32_combine / crc32_combine
     are associative but NOT commutative, so rank order is kept);
   * independent streams (pigz-style): stream i lives on rank i // per_rank; the exchange is an all-gather of
     the per-stream table {clen, check, ulen}, after which every rank can place any stream in a global archive
@@ -29,6 +29,30 @@ def gather_rows(row, group=None):
     out = torch.empty((world * row.numel(),), dtype=row.dtype, device=row.device)
     dist.all_gather_into_tensor(out, row, group=group)
     return out.view(world, row.numel())
+
+
+def gather_check_rows(row, out=None, group=None):
+    """all-gather one packed checksum row per rank: `row` = int32[4] holding a zng_rocm_check_row
+    {u32 adler, u32 crc, u64 len} (16 bytes).  Returns int32[world * 4] in rank order -- what
+    zng_rocm_combine_rows_dev folds.  `out` (preallocated, same device) makes the call allocation-free, so it can sit
+    on a side stream behind the checksum kernel (bench.py)."""
+    world, _ = _world(group)
+    row = row.contiguous()
+    if out is None:
+        out = torch.empty((world * 4,), dtype=torch.int32, device=row.device)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        out.copy_(row)
+        return out
+    dist.all_gather_into_tensor(out, row, group=group)
+    return out
+
+
+def check_rows_to_list(rows_i32):
+    """int32[world * 4] packed rows -> [[adler, crc, len], ...] (host ints)"""
+    out = []
+    for a, c, lo, hi in rows_i32.view(-1, 4).tolist():
+        out.append([a & 0xffffffff, c & 0xffffffff, (lo & 0xffffffff) | ((hi & 0xffffffff) << 32)])
+    return out
 
 
 def fold_checksums(rows):

@@ -51,6 +51,8 @@ _PROTOS = {
                                          C.c_void_p, C.c_void_p]),
     "zng_rocm_adler32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_crc32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_reserve_cus": (C.c_int, [C.c_int]),
+    "zng_rocm_combine_rows_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_slide_hash_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zng_rocm_compare256_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_update_hash_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
@@ -274,6 +276,19 @@ def adler32_combine_dev(checks, lens, out, stream=None):
     _need_init()
     _check(lib().zng_rocm_adler32_combine_dev(_dev_ptr(checks), _dev_ptr(lens), checks.numel(), _dev_ptr(out),
                                               _stream_ptr(stream)), "zng_rocm_adler32_combine_dev")
+
+
+def reserve_cus(n):
+    """leave n CUs out of the persistent checksum grid (for collectives / other streams); 0 = use all"""
+    _need_init()
+    _check(lib().zng_rocm_reserve_cus(int(n)), "zng_rocm_reserve_cus")
+
+
+def combine_rows_dev(rows, count, out2, stream=None):
+    """rows: device tensor of `count` packed {u32 adler, u32 crc, u64 len} rows (16 bytes each); out2: int32[2]"""
+    _need_init()
+    _check(lib().zng_rocm_combine_rows_dev(_dev_ptr(rows), count, _dev_ptr(out2), _stream_ptr(stream)),
+           "zng_rocm_combine_rows_dev")
 
 
 def crc32_combine_dev(checks, lens, out, stream=None):
