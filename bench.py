@@ -245,9 +245,14 @@ def main():
     rows_all = [torch.zeros(world * 4, dtype=torch.int32, device=dev) for _ in range(k_slots)]
     totals = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(k_slots)]
     side = torch.cuda.Stream(device=dev, priority=-1)    # its own hardware queue: must not share the main one
-    produced = [torch.cuda.Event() for _ in range(k_slots)]
-    released = [torch.cuda.Event() for _ in range(k_slots)]
-    state = {"k": 0}
+    # Cross-stream synchronisation is per GROUP of k_group steps, not per step: every step still has its own all-gather
+    # and its own combine, but an event-record packet in front of every checksum launch costs ~10 us of launch gap
+    # (traced), so the exchanges of a group are issued together behind one event.
+    k_group = 4
+    n_groups = k_slots // k_group
+    produced = [torch.cuda.Event() for _ in range(n_groups)]
+    released = [torch.cuda.Event() for _ in range(n_groups)]
+    state = {"k": 0, "last": 0}
 
     # Host cost matters as much as device cost here: a step is 0.18 ms of kernel, and every Python-side stream switch
     # or tensor op in the loop is tens of microseconds.  So inside the loop torch's *current* stream IS the exchange
@@ -256,35 +261,45 @@ def main():
     main = torch.cuda.current_stream()
     if multi and not rehearse:
         torch.cuda.set_stream(side)
-        # the checksum grid is one workgroup per CU for the whole pass: leave a few CUs to the exchange stream, or its
-        # kernels displace a workgroup the pass then waits for (measured on one GPU with a one-rank RCCL group:
-        # 0.225 ms per step with every CU taken)
-        zr.reserve_cus(int(os.environ.get("ZNG_BENCH_RESERVE_CUS", "8")))
+        # the checksum grid is one workgroup per CU for the whole pass: leave a few CUs to the exchange stream, so
+        # that the collective's workgroups do not have to displace one the pass then waits for
+        zr.reserve_cus(int(os.environ.get("ZNG_BENCH_RESERVE_CUS", "4")))
+
+    def exchange(group, count):
+        """the exchanges of `count` finished steps of this group: one all-gather + one combine each"""
+        produced[group].record(main)
+        side.wait_event(produced[group])
+        for j in range(count):
+            slot = group * k_group + j
+            par.gather_check_rows(rows_local[slot], rows_all[slot])      # RCCL all-gather on the exchange stream, 16 B per rank
+            zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=side)
+        released[group].record(side)
 
     def step():
         if not multi:
             zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
             return
         slot = state["k"] % k_slots
-        state["k"] += 1
+        group, pos = divmod(slot, k_group)
         row = rows_local[slot]
-        if slot == 0 and state["k"] > k_slots:
-            # once per round of slots: the exchange stream has finished with the previous round (its last release is
-            # the youngest), so every slot may be written again.  A wait per step would put a barrier packet in front
-            # of every checksum launch (measured: ~8 us each).
-            main.wait_event(released[k_slots - 1])
+        if pos == 0 and state["k"] >= k_slots and not rehearse:
+            main.wait_event(released[group])             # the exchange stream is done with this group's slots
         zr.adler32_crc32_dev(buf, row, adler=1, crc=0, stream=main)       # row[0:2] <- {adler, crc}
+        state["last"] = slot
+        state["k"] += 1
         if rehearse:
             # gloo has no device tensors: same payload and fold, synchronously through the host
             g = par.gather_check_rows(row.cpu()).to(dev)
             zr.combine_rows_dev(g, world, totals[slot], stream=main)
-            released[slot].record(main)
-            return
-        produced[slot].record(main)
-        side.wait_event(produced[slot])
-        par.gather_check_rows(row, rows_all[slot])       # RCCL all-gather on the current (= exchange) stream, 16 B per rank
-        zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=side)
-        released[slot].record(side)
+        elif pos == k_group - 1:
+            exchange(group, k_group)
+
+    def flush():
+        """exchanges of a partly filled group (step counts that are not a multiple of k_group)"""
+        pending = state["k"] % k_group
+        if multi and not rehearse and pending:
+            exchange((state["k"] % k_slots) // k_group, pending)
+            state["k"] += k_group - pending              # the next step starts a fresh group
 
     def fence():
         if world > 1:
@@ -293,12 +308,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush()
     fence()
     zr.trace_begin(args.steps)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = zr.trace_end(args.steps)
@@ -309,7 +326,7 @@ def main():
     elapsed = t.item()
 
     torch.cuda.set_stream(main)
-    last = (state["k"] - 1) % k_slots if multi else 0
+    last = state["last"] if multi else 0
     result = [v & 0xffffffff for v in (rows_local[last][0:2] if multi else out).tolist()]
     if multi:
         # the on-device ordered combine must equal the host fold of the gathered rows
