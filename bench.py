@@ -259,7 +259,10 @@ def main():
     # stream (the collective and the combine pick it up implicitly) and the checksum kernel is launched on `main`
     # explicitly -- no per-step stream context, no tensor arithmetic.
     main = torch.cuda.current_stream()
-    if multi and not rehearse:
+    # ZNG_BENCH_SIMPLE_EXCHANGE=1: no second stream -- kernel, all-gather and combine in order on the main stream
+    # (the plain form of the same step; kept as a switch so the overlapped form can be compared against it)
+    simple = os.environ.get("ZNG_BENCH_SIMPLE_EXCHANGE") == "1"
+    if multi and not rehearse and not simple:
         torch.cuda.set_stream(side)
         # the checksum grid is one workgroup per CU for the whole pass: leave a few CUs to the exchange stream, so
         # that the collective's workgroups do not have to displace one the pass then waits for
@@ -282,7 +285,7 @@ def main():
         slot = state["k"] % k_slots
         group, pos = divmod(slot, k_group)
         row = rows_local[slot]
-        if pos == 0 and state["k"] >= k_slots and not rehearse:
+        if pos == 0 and state["k"] >= k_slots and not rehearse and not simple:
             main.wait_event(released[group])             # the exchange stream is done with this group's slots
         zr.adler32_crc32_dev(buf, row, adler=1, crc=0, stream=main)       # row[0:2] <- {adler, crc}
         state["last"] = slot
@@ -291,13 +294,16 @@ def main():
             # gloo has no device tensors: same payload and fold, synchronously through the host
             g = par.gather_check_rows(row.cpu()).to(dev)
             zr.combine_rows_dev(g, world, totals[slot], stream=main)
+        elif simple:
+            par.gather_check_rows(row, rows_all[slot])   # current stream = main
+            zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=main)
         elif pos == k_group - 1:
             exchange(group, k_group)
 
     def flush():
         """exchanges of a partly filled group (step counts that are not a multiple of k_group)"""
         pending = state["k"] % k_group
-        if multi and not rehearse and pending:
+        if multi and not rehearse and not simple and pending:
             exchange((state["k"] % k_slots) // k_group, pending)
             state["k"] += k_group - pending              # the next step starts a fresh group
 
