@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the arch/rocm hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): crc32 + adler32 over a 1 GiB synthetic buffer that is
-already resident in HBM, block-parallel with on-device combine.  One "step" = one fused pass
-of `zng_rocm_adler32_crc32_dev` over the rank's 1 GiB shard (both checksums, bytes read once).
+Top-level line (BASELINE.json configs[1]): crc32 + adler32 over a 1 GiB synthetic buffer that is already resident
+in HBM, block-parallel with on-device combine.  One "step" = one fused pass of `zng_rocm_adler32_crc32_dev` over
+the rank's 1 GiB shard (both checksums, bytes read once).  N > 1: weak scaling -- every rank owns its own 1 GiB
+shard of one N GiB logical buffer; the only exchange is the all-gather of {adler, crc, len} (16 bytes per rank over
+RCCL) followed by the ordered on-device combine.
+
+The same line carries a `streams` object at every N (BASELINE.json configs[4], the north_star's multi-stream
+curve): 4096 independent 1 MiB streams, level-1 class, sharded over the N ranks (strong scaling), the {clen,
+adler32, ulen} table all-gathered over RCCL; `streams.value` at N = 1, 2, 4, 8 is the 1 -> 8 GPU scaling curve.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
-
-N > 1: weak scaling -- every rank owns its own 1 GiB shard of one N GiB logical buffer; the only
-exchange is the all-gather of {adler, crc, len} (12 bytes per rank over RCCL) followed by the
-ordered on-device combine.  Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import importlib
 import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,11 +32,32 @@ METRIC = "GB/s input throughput (adler32, crc32, deflate lvl6, inflate) @1/2/4/8
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SHARD_BYTES = 1 << 30           # cfg2: 1 GiB per GPU
 SEED = 0x5EED0002
+# LDS-heavy kernels reach their steady clock only after a few hundred launches (tools/micro/fused_steady.py: 5.39 ->
+# 6.10 TB/s over the first ~100).  The settle phase below is UNTIMED and disclosed in the line (`settle_launches`):
+# it runs before the W warm-up steps, so `--warmup 5` measures the same steady state a long warm-up does.
+SETTLE_LAUNCHES = 300
+TRACE_STRIDE = 8                # HIP-event pairs bracket every 8th launch of the timed loop, not every launch
+
+# the REAL reference (zlib-ng 2.2.2, cmake build, runtime dispatch to AVX-512 VNNI /
+# VPCLMULQDQ), measured in the survey container on one thread -- quoted for context, not measured by this script
+REFERENCE_CONTAINER = {
+    "what": "zlib-ng 2.2.2 itself, 1 thread, Xeon @2.1 GHz, survey container (BASELINE.md section 2); not re-measured here",
+    "adler32_GBps": 7.5, "crc32_GBps": 9.8, "deflate_level1_GBps": 0.171, "deflate_level6_GBps": 0.044,
+    "inflate_out_GBps": [0.318, 0.516],
+}
 
 
-def cpu_baseline(host_view, reps=3):
-    """oracle (port of adler32_c) + oracle/_ref (the reference's crc32_braid_c.c) on ONE host core,
-    over the same bytes the GPU step reads."""
+def host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_baseline(host_view, zr, reps=3):
+    """The CPU checker timed on this box's host cores over the step's own bytes: adler32 = the oracle port of
+    adler32_c.c, crc32 = the reference's crc32_braid_c.c (oracle/_ref) when it was built.  Two figures (BASELINE.md
+    section 3): one thread, and T threads each on its own contiguous slice folded with the combine operators."""
     import oracle_lib
     orc = oracle_lib.load()
     ref_crc = oracle_lib.load_ref_crc32()
@@ -52,17 +76,43 @@ def cpu_baseline(host_view, reps=3):
         tc.append(t2 - t1)
         pair.append(t2 - t0)
     gb = n / 1e9
+    T = host_threads()
+    cuts = [n * k // T for k in range(T + 1)]
+    part = [None] * T
+
+    def work(k):
+        p, ln = ptr + cuts[k], cuts[k + 1] - cuts[k]
+        part[k] = (orc.oracle_adler32(1, p, ln), crc_fn(0, p, ln), ln)
+
+    multi = []
+    am = cm = 0
+    for _ in range(reps):
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        am, cm = part[0][0], part[0][1]
+        for k in range(1, T):
+            am = zr.rocm.adler32_combine(am, part[k][0], part[k][2])
+            cm = zr.rocm.crc32_combine(cm, part[k][1], part[k][2])
+        multi.append(time.perf_counter() - t0)
+    assert (am, cm) == (a, c), "T-thread slices + combine differ from the one-thread value"
+    crc_name = "reference crc32_braid_c.c via oracle/_ref" if ref_crc is not None else "oracle port of crc32_braid_c.c"
     return {
         "value": round(gb / statistics.median(pair), 3),
         "unit": "GB/s",
         "cores": 1,
         "kind": "port",
         "sample": ("%d MiB of the step's own buffer, %d reps, median; one thread runs adler32 (oracle port of "
-                   "adler32_c.c) then crc32 (%s)" % (n >> 20, reps,
-                                                     "reference crc32_braid_c.c via oracle/_ref" if ref_crc is not None
-                                                     else "oracle port of crc32_braid_c.c")),
+                   "adler32_c.c) then crc32 (%s)" % (n >> 20, reps, crc_name)),
         "adler32_GBps": round(gb / statistics.median(ta), 3),
         "crc32_GBps": round(gb / statistics.median(tc), 3),
+        "multi": {"value": round(gb / statistics.median(multi), 3), "unit": "GB/s", "cores": T,
+                  "sample": "same buffer cut into %d contiguous slices, one thread each (all host cores this process "
+                            "may use), adler32 then crc32 per slice, folded with adler32_combine / crc32_combine" % T},
+        "reference_container": REFERENCE_CONTAINER,
     }, (a, c)
 
 
@@ -78,113 +128,171 @@ def pmc_traffic(kernel, nbytes):
                 doc = json.load(open(os.path.join(pdir, name)))
             except ValueError:
                 continue
-            k = doc.get("kernels", {}).get(kernel)
-            if k and doc.get("bytes_per_launch_algorithmic") == nbytes and "hbm_bytes_per_launch_corrected" in k:
-                best = {"bytes": k["hbm_bytes_per_launch_corrected"], "source": "profiles/" + name}
+            for kname, k in doc.get("kernels", {}).items():
+                if kname.startswith(kernel) and doc.get("bytes_per_launch_algorithmic") == nbytes \
+                        and "hbm_bytes_per_launch_corrected" in k:
+                    best = {"bytes": k["hbm_bytes_per_launch_corrected"], "source": "profiles/" + name}
     return best
 
 
-def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse):
+def copy_ceiling(torch, buf):
+    """measured device-copy ceiling of this box: a plain device-to-device copy of the step's
+    buffer, 2N bytes of HBM traffic per copy, timed with events after its own warm-up"""
+    dst = torch.empty_like(buf)
+    for _ in range(20):
+        dst.copy_(buf)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        dst.copy_(buf)
+    b.record()
+    b.synchronize()
+    ms = a.elapsed_time(b) / 20
+    del dst
+    return 2 * buf.numel() / 1e9 / (ms / 1e3)
+
+
+def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, warmup):
     """BASELINE.json configs[4]: `--streams` independent 1 MiB streams, level-1 class, sharded over the ranks
-    (strong scaling: the total is fixed).  Step = every rank compresses its shard (K1 parse + K2 static emit) and
-    the {clen, adler32, ulen} table is all-gathered (RCCL, 24 bytes per stream) and prefix-summed on every rank."""
+    (strong scaling: the total is fixed).  Step = every rank compresses its shard (LZ77 parse + static-Huffman emit)
+    and the {clen, adler32, ulen} table is all-gathered (RCCL, 24 bytes per stream) and prefix-summed on every rank.
+    Returns the `streams` object (rank 0) or None."""
     import zlib
 
     import numpy as np
     import synth
     dfl = importlib.import_module("zlib-ng_amd.deflate")
-    each = 1 << 20
+    each, distinct = 1 << 20, 96
     first, count = par.shard_streams(args.streams, world, rank)
     # stream i = slice (i mod 96) of a 96 MiB six-class mix (seed 0x5EED0005): every rank can rebuild any stream
-    base = synth.silesia_like(96 << 20, seed=0x5EED0005, seg_bytes=1 << 20)
-    idx = (np.arange(first, first + count) % 96)
-    host = np.concatenate([base[i * each:(i + 1) * each] for i in idx]) if count else np.zeros(16, dtype=np.uint8)
-    src = torch.from_numpy(host).to(dev)
+    base = synth.silesia_like(distinct << 20, seed=0x5EED0005, seg_bytes=1 << 20)
+    d_base = torch.from_numpy(base).to(dev).view(distinct, each)
+    idx = torch.arange(first, first + count, device=dev) % distinct
+    src = d_base[idx].reshape(-1).contiguous() if count else torch.zeros(16, dtype=torch.uint8, device=dev)
+    del d_base
     batch = dfl.QuickBatch(src, [i * each for i in range(count)], [each] * count)
     ulen = torch.full((count,), each, dtype=torch.int64, device=dev)
+    per = (args.streams + world - 1) // world
+    padded = torch.zeros((per, 3), dtype=torch.int64, device=dev)
+    gathered = torch.zeros((world * per * 3,), dtype=torch.int64, device=dev)
     state = {}
+
+    def exchange():
+        res = batch.results.to(torch.int64) & 0xffffffff
+        if count:
+            padded[:count, 0] = res[:, 0]
+            padded[:count, 1] = res[:, 1]
+            padded[:count, 2] = ulen
+        if world > 1 and not rehearse:
+            dist.all_gather_into_tensor(gathered, padded.view(-1))       # RCCL, 24 bytes per stream
+            table = gathered.view(world * per, 3)[:args.streams]
+        elif world > 1:
+            table = par.gather_rows(padded.view(-1).cpu()).view(world * per, 3)[:args.streams].to(dev)
+        else:
+            table = padded[:args.streams]
+        state["table"] = table
+        state["offsets"] = torch.cumsum(table[:, 0], 0) - table[:, 0]    # where each stream lands in one archive
 
     def step():
         batch.run()
-        res = batch.results.to(torch.int64) & 0xffffffff
-        local = torch.stack([res[:, 0], res[:, 1], ulen], dim=1) if count else torch.zeros((0, 3), dtype=torch.int64, device=dev)
-        if world > 1:
-            tab = local.cpu() if rehearse else local
-            state["table"] = par.gather_stream_table(tab, args.streams)
-        else:
-            state["table"] = (local, torch.cumsum(local[:, 0], 0) - local[:, 0], None)
+        exchange()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         step()
     fence()
-    zr.trace_begin(args.steps)
+    zr.rocm.lib().zng_rocm_trace_stride(1)
+    zr.trace_begin(steps)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = zr.trace_end(args.steps)
+    kernel_ms = zr.trace_end(steps)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
-    table = state["table"][0].cpu()
-    # parity on this rank: first and last local stream round-trip through an independent inflater
+    # the exchange by itself (latency bound: tens of KiB), reported separately as SURVEY.md 8e asks
+    fence()
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ea.record()
+    for _ in range(10):
+        exchange()
+    eb.record()
+    eb.synchronize()
+    exchange_us = ea.elapsed_time(eb) / 10 * 1e3
+    table = state["table"].cpu()
+    # parity on this rank: first and last local stream round-trip through an independent inflater, every local
+    # Adler-32 row equals that of its slice
     res = batch.results.cpu()
+    adlers = [zlib.adler32(base[k * each:(k + 1) * each].tobytes()) for k in range(distinct)]
+    for i in range(count):
+        assert (int(res[i, 1]) & 0xffffffff) == adlers[(first + i) % distinct], "adler32 row %d" % (first + i)
     for i in ([0, count - 1] if count else []):
-        assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == host[i * each:(i + 1) * each].tobytes()
-    if rank == 0:
-        total_in = args.streams * each
-        total_out = int(table[:, 0].sum())
-        k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
-        local_bytes = count * each + int(res[:, 0].to(torch.int64).sum())
-        line = {
-            "metric": METRIC, "value": round(total_in / 1e9 / (elapsed / args.steps), 2), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[4]: %d independent 1 MiB streams, deflate level-1 class (static Huffman), "
-                                   "sharded %d-way, {clen, adler32, ulen} table all-gathered" % (args.streams, world),
-                       "streams_per_gpu": count, "ratio": round(total_in / total_out, 3),
-                       "parallelism": "streams/%d+allgather(24B/stream)" % world, "rehearsal_same_gpu": rehearse},
-            "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (scalar-issue and barrier bound LZ77 front end, see DESIGN.md 3.4)",
-                         "achieved": round(local_bytes / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
-        }
-        if not args.no_cpu:
-            t0 = time.perf_counter()
-            done = 0
-            while time.perf_counter() - t0 < 10 and done < count:
-                zlib.compress(host[done * each:(done + 1) * each].tobytes(), 1)
-                done += 1
-            dt = time.perf_counter() - t0
-            line["cpu_baseline"] = {"value": round(done * each / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-                                    "sample": "%d of this rank's streams through CPython zlib level 1 (classic zlib 1.2.11, "
-                                              "an independent codec: zlib-ng itself cannot be built here), one thread" % done}
-        print(json.dumps(line), flush=True)
+        k = (first + i) % distinct
+        assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == base[k * each:(k + 1) * each].tobytes()
+    if rank != 0:
+        return None
+    total_in = args.streams * each
+    total_out = int(table[:, 0].sum())
+    assert int(table[:, 2].sum()) == total_in and int(state["offsets"][-1] + table[-1, 0]) == total_out
+    k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
+    local_bytes = count * each + int(res[:, 0].to(torch.int64).sum())
+    out = {
+        "workload": "configs[4]: %d independent 1 MiB streams, deflate level-1 class (static Huffman), sharded %d-way, "
+                    "{clen, adler32, ulen} table all-gathered" % (args.streams, world),
+        "value": round(total_in / 1e9 / (elapsed / steps), 2), "unit": "GB/s", "scaling": "strong",
+        "n_gpus": world, "steps": steps, "warmup": max(1, warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "streams_per_gpu": count, "ratio": round(total_in / total_out, 3),
+        "exchange_us": round(exchange_us, 1),
+        "exchange": "all_gather of %d B per rank (24 B per stream) + exclusive scan of clen on every rank; inside "
+                    "ms_per_step, also timed alone here" % (per * 24),
+        "parallelism": "streams/%d+allgather(24B/stream)" % world, "rehearsal_same_gpu": rehearse,
+        "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (LZ77 front end of the level-1 class, DESIGN.md 3.4)",
+                     "achieved": round(local_bytes / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
+    }
+    if not args.no_cpu:
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 8 and done < count:
+            zlib.compress(base[(done % distinct) * each:(done % distinct + 1) * each].tobytes(), 1)
+            done += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(done * each / 1e9 / dt, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                               "sample": "%d of this rank's streams through CPython zlib level 1 (classic zlib 1.2.11, an "
+                                         "independent codec: zlib-ng itself cannot be built under the round rules), one "
+                                         "thread" % done,
+                               "reference_container_GBps": REFERENCE_CONTAINER["deflate_level1_GBps"]}
+    del batch, src
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=200)   # LDS-heavy kernels reach their steady clock after ~100 launches (tools/micro/fused_steady.py)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shard-mib", type=int, default=SHARD_BYTES >> 20)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--workload", choices=("checksum", "streams"), default="checksum",
-                    help="checksum = BASELINE.json configs[1] (default, the driver's contract); "
-                         "streams = configs[4]: 4096 x 1 MiB level-1 class deflate sharded over the ranks")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--workload", choices=("all", "checksum", "streams"), default="all",
+                    help="all = BASELINE.json configs[1] as the top-level line (the driver's contract) plus the "
+                         "configs[4] `streams` object; checksum = the top-level line only; streams = configs[4] only, "
+                         "printed as the line")
     ap.add_argument("--streams", type=int, default=4096)
+    ap.add_argument("--stream-steps", type=int, default=0, help="timed steps of the streams leg (0 = min(steps, 6))")
     args = ap.parse_args()
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
@@ -217,9 +325,21 @@ def main():
     zr = importlib.import_module("zlib-ng_amd")      # raises if libzng_rocm.so is missing: no fallback
     zr.init(local_rank)
     par = importlib.import_module("zlib-ng_amd.parallel")
+    stream_steps = args.stream_steps or max(1, min(args.steps, 6))
+    stream_warm = max(1, min(args.warmup, 2))
 
     if args.workload == "streams":
-        run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse)
+        s = run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, args.steps, args.warmup)
+        if rank == 0:
+            line = {"metric": METRIC, "value": s["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": max(1, args.warmup), "ms_per_step": s["ms_per_step"], "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                    "config": {"workload": s["workload"], "streams_per_gpu": s["streams_per_gpu"], "ratio": s["ratio"],
+                               "parallelism": s["parallelism"], "rehearsal_same_gpu": rehearse},
+                    "roofline": s["roofline"], "exchange_us": s["exchange_us"]}
+            if "cpu_baseline" in s:
+                line["cpu_baseline"] = s["cpu_baseline"]
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -258,10 +378,16 @@ def main():
     # or tensor op in the loop is tens of microseconds.  So inside the loop torch's *current* stream IS the exchange
     # stream (the collective and the combine pick it up implicitly) and the checksum kernel is launched on `main`
     # explicitly -- no per-step stream context, no tensor arithmetic.
-    main = torch.cuda.current_stream()
+    main_stream = torch.cuda.current_stream()
     # ZNG_BENCH_SIMPLE_EXCHANGE=1: no second stream -- kernel, all-gather and combine in order on the main stream
     # (the plain form of the same step; kept as a switch so the overlapped form can be compared against it)
     simple = os.environ.get("ZNG_BENCH_SIMPLE_EXCHANGE") == "1"
+
+    # ---- settle phase: untimed, disclosed (`settle_launches`) --------------------------------------------------
+    for _ in range(SETTLE_LAUNCHES):
+        zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
+    torch.cuda.synchronize()
+
     if multi and not rehearse and not simple:
         torch.cuda.set_stream(side)
         # the checksum grid is one workgroup per CU for the whole pass: leave a few CUs to the exchange stream, so
@@ -270,7 +396,7 @@ def main():
 
     def exchange(group, count):
         """the exchanges of `count` finished steps of this group: one all-gather + one combine each"""
-        produced[group].record(main)
+        produced[group].record(main_stream)
         side.wait_event(produced[group])
         for j in range(count):
             slot = group * k_group + j
@@ -286,17 +412,17 @@ def main():
         group, pos = divmod(slot, k_group)
         row = rows_local[slot]
         if pos == 0 and state["k"] >= k_slots and not rehearse and not simple:
-            main.wait_event(released[group])             # the exchange stream is done with this group's slots
-        zr.adler32_crc32_dev(buf, row, adler=1, crc=0, stream=main)       # row[0:2] <- {adler, crc}
+            main_stream.wait_event(released[group])      # the exchange stream is done with this group's slots
+        zr.adler32_crc32_dev(buf, row, adler=1, crc=0, stream=main_stream)       # row[0:2] <- {adler, crc}
         state["last"] = slot
         state["k"] += 1
         if rehearse:
             # gloo has no device tensors: same payload and fold, synchronously through the host
             g = par.gather_check_rows(row.cpu()).to(dev)
-            zr.combine_rows_dev(g, world, totals[slot], stream=main)
+            zr.combine_rows_dev(g, world, totals[slot], stream=main_stream)
         elif simple:
             par.gather_check_rows(row, rows_all[slot])   # current stream = main
-            zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=main)
+            zr.combine_rows_dev(rows_all[slot], world, totals[slot], stream=main_stream)
         elif pos == k_group - 1:
             exchange(group, k_group)
 
@@ -316,6 +442,8 @@ def main():
         step()
     flush()
     fence()
+    stride = TRACE_STRIDE if args.steps >= 4 * TRACE_STRIDE else 1
+    zr.rocm.lib().zng_rocm_trace_stride(stride)
     zr.trace_begin(args.steps)
     fence()
     t0 = time.perf_counter()
@@ -325,13 +453,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = zr.trace_end(args.steps)
+    zr.rocm.lib().zng_rocm_trace_stride(1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
-    torch.cuda.set_stream(main)
+    torch.cuda.set_stream(main_stream)
     last = state["last"] if multi else 0
     result = [v & 0xffffffff for v in (rows_local[last][0:2] if multi else out).tolist()]
     if multi:
@@ -343,10 +472,11 @@ def main():
         got_total = [v & 0xffffffff for v in totals[last].tolist()]
         assert got_total == [folded[0], folded[1]], (got_total, folded)
         assert rows[rank][:2] == result and all(r[2] == n for r in rows)
+        zr.reserve_cus(0)
     # separate single-checksum timings (outside the timed region, informational)
     extra = {}
     for name, fn in (("adler32", lambda: zr.adler32_dev(buf, out)), ("crc32", lambda: zr.crc32_dev(buf, out))):
-        for _ in range(3):
+        for _ in range(50):
             fn()
         torch.cuda.synchronize()
         zr.trace_begin(20)
@@ -354,12 +484,15 @@ def main():
             fn()
         ms = zr.trace_end(20)
         extra[name + "_kernel_GBps"] = round(n / 1e9 / (statistics.mean(ms) / 1e3), 1)
+    measured_copy = copy_ceiling(torch, buf) if rank == 0 else None
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n / 1e9 / (elapsed / args.steps)
         k_avg_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
         achieved = n / 1e9 / (k_avg_ms / 1e3)
+        traffic = pmc_traffic("zr::stream_kernel<true, true, false", n) or {}
         line = {
             "metric": METRIC,
             "value": round(value, 2),
@@ -367,6 +500,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_launches": SETTLE_LAUNCHES,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -381,6 +515,8 @@ def main():
                 if multi else "single",
                 "checksums": ["%08x" % result[0], "%08x" % result[1]],
                 "rehearsal_same_gpu": rehearse,
+                "settle": "%d untimed launches of the same kernel before the %d warm-up steps (clock settle, not part of "
+                          "any timed figure)" % (SETTLE_LAUNCHES, args.warmup),
             },
             "roofline": {
                 "bound": "hbm",
@@ -389,19 +525,32 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": (pmc_traffic("zr::stream_kernel<true, true, false>", n) or {}).get("bytes"),
-                "traffic_source": (pmc_traffic("zr::stream_kernel<true, true, false>", n) or {}).get("source"),
+                "traffic": traffic.get("bytes"),
+                "traffic_source": traffic.get("source"),
                 "algorithmic_bytes_per_launch": n,
                 "avg_kernel_ms": round(k_avg_ms, 5),
                 "launches_timed": len(kernel_ms),
+                "launches_sampled_every": stride,
+                "measured_copy_GBps": round(measured_copy, 1),
+                "frac_of_measured_copy": round(achieved / measured_copy, 4),
+                "measured_copy": "torch device-to-device copy of the same %d MiB buffer, 2N bytes per copy, on this box" % (n >> 20),
             },
         }
         line.update(extra)
         if not args.no_cpu:
             host = buf.cpu().numpy()
-            cb, (a, c) = cpu_baseline(host)
+            cb, (a, c) = cpu_baseline(host, zr)
             assert [a, c] == result, "GPU result differs from the CPU checker: %r vs %r" % (result, [a, c])
             line["cpu_baseline"] = cb
+            del host
+
+    if args.workload == "all":
+        del buf
+        torch.cuda.empty_cache()
+        s = run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, stream_steps, stream_warm)
+        if rank == 0:
+            line["streams"] = s
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
     if world > 1 or force_dist:

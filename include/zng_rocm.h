@@ -10,12 +10,14 @@
  * Two families of entry points:
  *
  *  1. `zng_rocm_<slot>`: the functable slot itself, same argument meaning as the
- *     reference slot, HOST pointers.  Data is staged to the device, the HIP
- *     kernel runs, the answer comes back.  They never compute on the CPU: if the
- *     device is unusable they abort() with a message (a functable slot has no
- *     error channel; the integration stub only installs them after
- *     zng_rocm_init() returned 0, and keeps zlib-ng's own CPU tier for calls
- *     below its size threshold).
+ *     reference slot, HOST pointers.  Data is staged to the device through a
+ *     bounded (16 MiB) staging chunk, the HIP kernel runs, the answer comes back.
+ *     They never compute on the CPU: if the device is unusable they abort() with
+ *     a message (a functable slot has no error channel).  Each has a twin
+ *     `zng_rocm_<slot>_try` that returns a ZNG_ROCM_E* code instead of aborting,
+ *     which is what the reference-side adapter binds so that it can fall back to
+ *     zlib-ng's own CPU tier ("any HIP failure must degrade to the
+ *     CPU implementation").
  *
  *  2. `zng_rocm_<slot>_dev`: the same operation on data ALREADY RESIDENT IN HBM
  *     (device pointers), asynchronous on a caller-supplied HIP stream
@@ -54,6 +56,11 @@ const char *zng_rocm_last_error(void);
 /* {CUs, LDS bytes per CU, wavefront size, XCDs} of the initialised device */
 int         zng_rocm_device_info(int32_t out[4]);
 int         zng_rocm_shutdown(void);
+/* Per-stream state (partials, scratch of the stream-level entry points, staging) is created lazily for every HIP
+ * stream a *_dev call is given and kept until zng_rocm_shutdown().  A caller that destroys one of its streams
+ * releases that state first with this call (it synchronises the stream).  The host-pointer slots use one stream
+ * per host thread and release it themselves when the thread ends. */
+int         zng_rocm_stream_release(void *stream);
 /* The checksum kernels run one workgroup per CU for the whole pass.  A caller that overlaps them with work on
  * other HIP streams of the same device (an RCCL collective, the combine of the previous step) asks for `n` CUs
  * to be left out of that grid, so the other stream's kernels do not have to displace a workgroup the whole pass
@@ -78,6 +85,15 @@ uint32_t zng_rocm_crc32_fold_reset(zng_rocm_crc32_fold_t *crc);
 void     zng_rocm_crc32_fold(zng_rocm_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc);
 void     zng_rocm_crc32_fold_copy(zng_rocm_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len);
 uint32_t zng_rocm_crc32_fold_final(zng_rocm_crc32_fold_t *crc);
+
+/* The same slots with an error channel (no reference counterpart: a functable slot returns a value only).
+ * 0 and the value through *out / the updated fold state, or a negative ZNG_ROCM_E* code with nothing written and
+ * the fold state unchanged; never abort().  NULL buffers behave as in the slot (adler32 -> 1, crc32 -> 0). */
+int zng_rocm_adler32_try(uint32_t adler, const uint8_t *buf, size_t len, uint32_t *out);
+int zng_rocm_adler32_fold_copy_try(uint32_t adler, uint8_t *dst, const uint8_t *src, size_t len, uint32_t *out);
+int zng_rocm_crc32_try(uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out);
+int zng_rocm_crc32_fold_try(zng_rocm_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc);
+int zng_rocm_crc32_fold_copy_try(zng_rocm_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len);
 
 /* ---- checksums on device-resident data --------------------------------- */
 /* d_out: device pointer to one uint32_t.  Same value as the slot on the same
@@ -214,9 +230,14 @@ int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs,
  * complete, so it is compressed as parallel 128-512 KiB segments (hash primed with the preceding 32 KiB,
  * so matches cross segment borders) into one continuous raw RFC 1951 stream: per segment one block whose
  * type is chosen as zng_tr_flush_block does (stored / static / dynamic, trees.c:660-719), followed by an
- * empty stored block where byte alignment needs it (as Z_SYNC_FLUSH), and a final empty static block.  `level` 2..9 selects max_chain_length as deflate.c:142-168 does (capped
- * at 256).  d_out needs zng_rocm_deflate_bound(in_len) bytes.  Synchronises `stream` (the segment
- * lengths are prefix-summed on the host).  Returns 0, a ZNG_ROCM_E* code, or -5 (Z_BUF_ERROR). */
+ * empty stored block where byte alignment needs it (as Z_SYNC_FLUSH), and a final empty static block.
+ * `level` 2..9 selects max_chain_length and good_match as deflate.c:142-168 does (chain capped at 256); level 1 is
+ * deflate_quick's matcher (one probe of the chain head, deflate_quick.c:89-97) on the same segment scheme; level 0
+ * is deflate_stored (deflate_stored.c:27-186): stored blocks of MAX_STORED = 65535 bytes, the last one final -- the
+ * split that function makes when input and output are both complete (:46-95).  d_out needs
+ * zng_rocm_deflate_bound(in_len) bytes.
+ * Synchronises `stream` (the segment lengths are prefix-summed on the host).  Returns 0, a ZNG_ROCM_E* code, or
+ * -5 (Z_BUF_ERROR). */
 size_t zng_rocm_deflate_bound(size_t source_len);
 int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
                             size_t *out_len, void *stream);
@@ -267,12 +288,15 @@ int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst,
 /* ---- compress2 / uncompress2 class front ends (compress.c:31-98, uncompr.c:25-76) ---------------------
  * `format`: 0 = raw deflate, 1 = zlib (RFC 1950), 2 = gzip (RFC 1952).  The trailer checksum (Adler-32 /
  * CRC-32 + ISIZE) is computed by the device checksum kernel over the device-resident plaintext.
- * compress2_dev:   d_src (device) -> d_dst (device, *dst_len >= zng_rocm_compress_bound()); level as compress2
- *                  (-1 = 6; levels below 2 use the level-2 matcher).  Returns Z_OK (0) / Z_BUF_ERROR (-5) / error.
+ * compress2_dev:   d_src (device) -> d_dst (device, *dst_len >= zng_rocm_compress_bound()); level as compress2:
+ *                  -1 = 6, 0 = stored blocks, 1..9 as zng_rocm_deflate_dev, anything else Z_STREAM_ERROR (-2,
+ *                  deflate.c:318-320); the zlib FLEVEL / gzip XFL hints are those of the requested level
+ *                  (deflate.c:868-885, :913).  Returns Z_OK (0) / Z_BUF_ERROR (-5) / error.
  * uncompress2_dev: src (HOST, the sequential bitstream stays on the host) -> d_dst (device).  On return *dst_len
  *                  = plaintext bytes, *src_len = input bytes consumed.  Z_OK, Z_BUF_ERROR (destination too small),
  *                  Z_DATA_ERROR with the reference's message text in zng_rocm_last_error() ("incorrect header
- *                  check", "incorrect data check", "incorrect length check", decoder messages, incomplete stream). */
+ *                  check", "header crc mismatch" (gzip FHCRC, inflate.c:686-692), "incorrect data check",
+ *                  "incorrect length check", decoder messages, incomplete stream). */
 size_t zng_rocm_compress_bound(size_t source_len, int format);
 int    zng_rocm_compress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *d_src, size_t src_len, int level,
                               int format, void *stream);
@@ -289,6 +313,10 @@ int    zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *
  * reference measures with Google Benchmark, test/benchmarks/). */
 int zng_rocm_trace_begin(int max_launches);
 int zng_rocm_trace_end(float *ms_out, int cap);
+/* Bracket only every n-th marked launch (n >= 1; 1 = all, the default): an event pair in front of and behind a
+ * launch costs launch gap, so a timed loop samples its kernel instead of perturbing every step.  Takes effect at
+ * the next zng_rocm_trace_begin(). */
+int zng_rocm_trace_stride(int n);
 
 #ifdef __cplusplus
 }

@@ -51,3 +51,28 @@ def test_host_combine_matches_oracle(oracle):
         assert op == oracle.oracle_crc32_combine_gen(n)
         assert zr.crc32_combine_op(c1, c2, op) == oracle.oracle_crc32_combine_op(c1, c2, op)
     assert zr.adler32_combine(1, 1, -5) == 0xffffffff
+
+
+def test_try_forms_report_instead_of_aborting():
+    """zng_rocm_<slot>_try: the error channel the reference-side adapter falls back on.  Without a
+    device they return ZNG_ROCM_ENODEV and leave outputs and fold state alone; the process survives."""
+    import ctypes as C
+    zr = _product()
+    if zr.device_count() > 0:
+        return                                    # device behaviour is covered by the gpu tests
+    h = zr.lib()
+    buf = (C.c_uint8 * 64)(*range(64))
+    out = C.c_uint32(0xaaaaaaaa)
+    assert h.zng_rocm_adler32_try(1, buf, 64, C.byref(out)) == -1 and out.value == 0xaaaaaaaa
+    assert h.zng_rocm_crc32_try(0, buf, 64, C.byref(out)) == -1 and out.value == 0xaaaaaaaa
+    dst = (C.c_uint8 * 64)()
+    assert h.zng_rocm_adler32_fold_copy_try(1, dst, buf, 64, C.byref(out)) == -1 and bytes(dst) == bytes(64)
+    st = zr.rocm.Crc32FoldState()
+    st.value = 0x1234
+    assert h.zng_rocm_crc32_fold_try(C.byref(st), buf, 64, 0) == -1 and st.value == 0x1234
+    assert h.zng_rocm_crc32_fold_copy_try(C.byref(st), dst, buf, 64) == -1 and st.value == 0x1234
+    # NULL buffers keep the slot's meaning (adler32_c.c:24-25, crc32.c:22,28) and need no device
+    assert h.zng_rocm_adler32_try(5, None, 10, C.byref(out)) == 0 and out.value == 1
+    assert h.zng_rocm_crc32_try(5, None, 10, C.byref(out)) == 0 and out.value == 0
+    assert h.zng_rocm_adler32_try(1, buf, 64, None) == -3
+    assert h.zng_rocm_stream_release(None) == 0 and h.zng_rocm_shutdown() == 0

@@ -286,3 +286,51 @@ def test_combine_rows_dev(zr, oracle):
     out = torch.zeros(2, dtype=torch.int32, device="cuda")
     zr.combine_rows_dev(torch.from_numpy(rows.view(np.int32).copy()).cuda(), 3, out)
     assert [v & 0xffffffff for v in out.tolist()] == [a, c]
+
+
+def test_try_forms_and_bounded_staging(zr, oracle):
+    """zng_rocm_<slot>_try (the error channel the reference-side adapter binds) returns the slot's value; the
+    host-pointer path goes through one bounded 16 MiB staging chunk with the seed chained on the device, so sizes
+    around and above the chunk -- and non-canonical seeds across chunk borders -- must still be bit-exact."""
+    import ctypes as C
+    h = zr.lib()
+    out = C.c_uint32(0)
+    chunk = 16 << 20
+    for n in (0, 1, 15, chunk - 1, chunk, chunk + 1, 2 * chunk + 12345, 3 * chunk):
+        buf = seeded_bytes(n + 1, seed=4000 + n % 97)[:n]
+        p = buf.ctypes.data if n else seeded_bytes(1, 1).ctypes.data
+        for seed_a, seed_c in ((1, 0), (0xdeadc0de, 0xffffffff), (0xffffffff, 0x12345678)):
+            assert h.zng_rocm_adler32_try(seed_a, p, n, C.byref(out)) == 0
+            assert out.value == oracle.oracle_adler32(seed_a, p, n), (n, hex(seed_a))
+            assert h.zng_rocm_crc32_try(seed_c, p, n, C.byref(out)) == 0
+            assert out.value == oracle.oracle_crc32(seed_c, p, n), (n, hex(seed_c))
+    n = 2 * chunk + 777
+    src = seeded_bytes(n, seed=77)
+    dst = np.zeros(n + 32, dtype=np.uint8)
+    dst[:] = 0xA5
+    assert h.zng_rocm_adler32_fold_copy_try(1, dst.ctypes.data + 16, src.ctypes.data, n, C.byref(out)) == 0
+    assert out.value == oracle.oracle_adler32(1, src.ctypes.data, n)
+    assert bytes(dst[16:16 + n]) == bytes(src) and set(dst[:16]) == {0xA5} and set(dst[16 + n:]) == {0xA5}
+    st = zr.rocm.Crc32FoldState()
+    h.zng_rocm_crc32_fold_reset(C.byref(st))
+    assert h.zng_rocm_crc32_fold_try(C.byref(st), src.ctypes.data, chunk + 5, 0) == 0
+    dst[:] = 0
+    assert h.zng_rocm_crc32_fold_copy_try(C.byref(st), dst.ctypes.data, src.ctypes.data + chunk + 5, n - chunk - 5) == 0
+    assert h.zng_rocm_crc32_fold_final(C.byref(st)) == oracle.oracle_crc32(0, src.ctypes.data, n)
+    assert bytes(dst[:n - chunk - 5]) == bytes(src[chunk + 5:])
+    assert h.zng_rocm_adler32_try(1, src.ctypes.data, n, None) == -3
+
+
+def test_slots_from_a_thread_that_never_selected_the_device(zr, oracle):
+    """HIP's current device is per host thread; a slot call from a fresh thread must still land on the backend's
+    device.  On a one-GPU box the observable part is that fresh threads work and release their
+    per-thread stream when they end."""
+    import threading
+    buf = seeded_bytes((5 << 20) + 3, seed=9)
+    want = oracle.oracle_crc32(0, buf.ctypes.data, buf.size)
+    got = []
+    for _ in range(6):
+        t = threading.Thread(target=lambda: got.append(zr.crc32_z(0, buf)))
+        t.start()
+        t.join()
+    assert got == [want] * 6

@@ -1,0 +1,196 @@
+// crc_phases.hip -- times the streaming checksum kernel variant by variant (checksum_kernel.h: bit mask V) and
+// prints where a launch spends its time (in-kernel wall_clock64 stamps of workgroup-thread 0).
+// Standalone: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../zlib-ng_amd/csrc crc_phases.hip -o bin/crc_phases
+//   ./bin/crc_phases [MiB ...]        default sizes 64 256 1024
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "checksum_kernel.h"
+#include "tables.h"
+
+using namespace zr;
+
+namespace zr {
+void set_error(const char *, ...) {}
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ void fill_kernel(uint32_t *p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 31;
+        p[i] = (uint32_t)(z * 0x94D049BB133111EBull >> 16);
+    }
+}
+
+__global__ __launch_bounds__(1024) void null_kernel(Partial *p) {
+    if (threadIdx.x == 0 && blockIdx.x == 1u << 30) p[0].pad = 1;
+}
+
+struct Run {
+    const char *name;
+    void (*launch)(StreamArgs, const DeviceTables *, Partial *, int groups, hipStream_t);
+    bool crc, adler, profile;
+};
+
+template <bool A, bool C, int V, bool P>
+static void launcher(StreamArgs sa, const DeviceTables *t, Partial *p, int groups, hipStream_t st) {
+    hipLaunchKernelGGL((stream_kernel<A, C, false, V, P>), dim3(groups), dim3(kWgThreads), 0, st, sa, t, p);
+}
+
+int main(int argc, char **argv) {
+    std::vector<size_t> sizes;
+    for (int i = 1; i < argc; ++i) sizes.push_back((size_t)atol(argv[i]) << 20);
+    if (sizes.empty()) sizes = {64u << 20, 256u << 20, 1024u << 20};
+    const size_t maxn = *std::max_element(sizes.begin(), sizes.end());
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs\n", prop.gcnArchName, cus);
+
+    uint8_t *buf;
+    CK(hipMalloc(&buf, maxn + 4096));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t *)buf, (maxn + 4096) / 4);
+    static DeviceTables host_tabs;
+    build_tables(host_tabs);
+    DeviceTables *tabs;
+    CK(hipMalloc(&tabs, sizeof(DeviceTables)));
+    CK(hipMemcpy(tabs, &host_tabs, sizeof(DeviceTables), hipMemcpyHostToDevice));
+    Partial *partials;
+    CK(hipMalloc(&partials, sizeof(Partial) * kMaxGroups));
+    unsigned long long *stamps;
+    CK(hipMalloc(&stamps, 8 * sizeof(unsigned long long) * kMaxGroups));
+    uint32_t *out;
+    CK(hipMalloc(&out, 16));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+
+    const Run runs[] = {
+        {"adler32", launcher<true, false, 0, false>, false, true, false},
+        {"crc32 V=0 (round-1 form)", launcher<false, true, 0, false>, true, false, false},
+        {"crc32 V=1 both buffers first", launcher<false, true, 1, false>, true, false, false},
+        {"crc32 V=2 x32-table fold", launcher<false, true, 2, false>, true, false, false},
+        {"crc32 V=4 early partial products", launcher<false, true, 4, false>, true, false, false},
+        {"crc32 V=7 all three", launcher<false, true, 7, false>, true, false, false},
+        {"crc32 V=7+16 no replication (timing only)", launcher<false, true, 7 | 16, false>, true, false, false},
+        {"crc32 V=7+32 no multiply (timing only)", launcher<false, true, 7 | 32, false>, true, false, false},
+        {"crc32 V=7+48 neither (timing only)", launcher<false, true, 7 | 48, false>, true, false, false},
+        {"fused V=0", launcher<true, true, 0, false>, true, true, false},
+        {"fused V=7", launcher<true, true, 7, false>, true, true, false},
+        {"adler32 PROFILE", launcher<true, false, 0, true>, false, true, true},
+        {"crc32 V=0 PROFILE", launcher<false, true, 0, true>, true, false, true},
+        {"crc32 V=7 PROFILE", launcher<false, true, 7, true>, true, false, true},
+    };
+
+    const int WARM = 300, REPS = 200;
+    std::vector<hipEvent_t> ea(REPS), eb(REPS);
+    for (int i = 0; i < REPS; ++i) {
+        CK(hipEventCreate(&ea[i]));
+        CK(hipEventCreate(&eb[i]));
+    }
+    for (size_t n : sizes) {
+        printf("\n== %zu MiB ==\n", n >> 20);
+        StreamArgs sa;
+        sa.a0 = buf;
+        sa.dst0 = nullptr;
+        sa.n = (long long)n;
+        sa.body = (long long)n;
+        sa.nunits = (sa.body + kUnitBytes - 1) / kUnitBytes;
+        sa.head = 0;
+        sa.tail = 0;
+        sa.phase_stamps = stamps;
+        int groups = cus;
+        if (sa.nunits < groups) groups = (int)sa.nunits;
+        FinalArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.tail_base = buf + n;
+        fa.n = sa.n;
+        fa.nunits = sa.nunits;
+        fa.groups = groups;
+        fa.adler_seed = 1;
+        fa.crc_seed = 0;
+        fa.crc_len_pow = xpow_bytes(host_tabs.pow_tab, (uint64_t)n);
+
+        // launch floor: an empty kernel of the same shape
+        for (int i = 0; i < WARM; ++i) hipLaunchKernelGGL(null_kernel, dim3(groups), dim3(kWgThreads), 0, st, partials);
+        for (int i = 0; i < REPS; ++i) {
+            CK(hipEventRecord(ea[i], st));
+            hipLaunchKernelGGL(null_kernel, dim3(groups), dim3(kWgThreads), 0, st, partials);
+            CK(hipEventRecord(eb[i], st));
+        }
+        CK(hipStreamSynchronize(st));
+        {
+            double sum = 0;
+            for (int i = 0; i < REPS; ++i) {
+                float ms;
+                CK(hipEventElapsedTime(&ms, ea[i], eb[i]));
+                sum += ms;
+            }
+            printf("%-46s %8.2f us\n", "empty kernel, same grid (event floor)", sum / REPS * 1e3);
+        }
+        uint32_t ref_crc = 0, ref_adler = 0;
+        for (const Run &r : runs) {
+            fa.do_adler = r.adler;
+            fa.do_crc = r.crc;
+            auto step = [&]() {
+                r.launch(sa, tabs, partials, groups, st);
+                hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, fa, tabs, partials, out, out + 1);
+            };
+            for (int i = 0; i < WARM; ++i) step();
+            for (int i = 0; i < REPS; ++i) {
+                CK(hipEventRecord(ea[i], st));
+                r.launch(sa, tabs, partials, groups, st);
+                CK(hipEventRecord(eb[i], st));
+                hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, fa, tabs, partials, out, out + 1);
+            }
+            CK(hipStreamSynchronize(st));
+            std::vector<float> ms(REPS);
+            double sum = 0;
+            for (int i = 0; i < REPS; ++i) {
+                CK(hipEventElapsedTime(&ms[i], ea[i], eb[i]));
+                sum += ms[i];
+            }
+            std::sort(ms.begin(), ms.end());
+            uint32_t h[2];
+            CK(hipMemcpy(h, out, 8, hipMemcpyDeviceToHost));
+            const double us = sum / REPS * 1e3;
+            const char *verdict = "";
+            if (r.crc) {
+                if (!ref_crc) ref_crc = h[1];
+                verdict = h[1] == ref_crc ? " crc ok" : " crc DIFFERS (expected for timing-only variants)";
+            }
+            if (r.adler) {
+                if (!ref_adler) ref_adler = h[0];
+                if (h[0] != ref_adler) verdict = " ADLER DIFFERS";
+            }
+            printf("%-46s %8.2f us (median %7.2f)  %6.3f of 8 TB/s%s\n", r.name, us, ms[REPS / 2] * 1e3,
+                   (double)n / 1e9 / (us * 1e-6) / 8000.0, verdict);
+            if (r.profile) {
+                std::vector<unsigned long long> hs(8 * (size_t)groups);
+                CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t_end = 0;
+                for (int g = 0; g < groups; ++g) {
+                    t0 = std::min(t0, hs[8 * g]);
+                    t_end = std::max(t_end, hs[8 * g + 5]);
+                }
+                // wall_clock64 ticks at 100 MHz: 10 ns per tick
+                static const char *names[6] = {"start", "tables staged", "image built", "main loop done", "lane products done", "partial written"};
+                printf("    kernel span first start -> last end: %.2f us; per workgroup, us after the first start (min / median / max):\n",
+                       (double)(t_end - t0) / 100.0);
+                for (int k = 0; k < 6; ++k) {
+                    std::vector<double> v(groups);
+                    for (int g = 0; g < groups; ++g) v[g] = (double)(hs[8 * g + k] - t0) / 100.0;
+                    std::sort(v.begin(), v.end());
+                    printf("      %-20s %6.2f / %6.2f / %6.2f\n", names[k], v[0], v[groups / 2], v[groups - 1]);
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -1,396 +1,13 @@
-// checksum.hip -- Adler-32 / CRC-32 on gfx950: block-parallel streaming kernels with
-// on-device combine.
-//
-// Replaces, behind the functable boundary (functable.h:26-42):
-//   adler32            arch/generic/adler32_c.c:11-54
-//   crc32              arch/generic/crc32_braid_c.c:62-216
-//   adler32_fold_copy  arch/generic/adler32_fold_c.c:11-15
-//   crc32_fold_copy    arch/generic/crc32_fold_c.c:15-18
-// and evaluates the combine identities of adler32.c:32-54 / crc32_braid_comb.c:16-18
-// on the device.
-//
-// Data layout.  The message [buf, buf+n) is cut on 16-byte address granules:
-//   a0        = buf rounded down to 16        (first granule; its bytes below buf are masked to 0)
-//   tail_base = (buf+n) rounded down to 16    (the <16 trailing bytes are folded in by the finalize kernel)
-//   body      = [a0, tail_base), consumed in UNITS of 16 KiB = 1024 lanes x one dwordx4 each,
-//               units right-aligned to tail_base (a partial unit can only be the FIRST one, and
-//               missing leading pieces behave as leading zero bytes, which change neither checksum).
-// Workgroup g owns a contiguous run of units; per step its 1024 lanes read one fully
-// coalesced 16 KiB row.  Each lane therefore sees a strided sub-stream (stride 16 KiB):
-//   CRC:   four braids per lane (the four dwords of its piece).  One step is the braid step of
-//          crc32_braid_c.c:121-176 with the stride n*w = 16 KiB:  s <- s * x^(8*16384) ^ word,
-//          done with four byte-indexed tables held in LDS, each replicated over the 32 banks
-//          (entry e of lane l at bank l%32) so that every ds_read_b32 is conflict-free.
-//   Adler: lane-local byte sum A (v_sad_u8) and in-piece weighted sum (v_dot4_u32_u8); positions
-//          are applied in closed form, B = sum (n - pos) * byte, so blocks combine by plain addition
-//          (the linear form of adler32_combine_).
-// Each workgroup weights its CRC partial to the end of the body (x^(8 * 16 KiB * units_after), two table
-// multiplies) and leaves one Partial; the small finalize kernel XORs / sums them, folds the tail bytes and
-// the seed (whose image ~seed * x^(8n) the host evaluates) and writes the checksum(s) to device memory.
+// checksum.hip -- host launcher of the streaming Adler-32 / CRC-32 kernels (checksum_kernel.h) and their
+// *_dev entry points; the combine identities of adler32.c:32-54 / crc32_braid_comb.c:16-18 are evaluated on the
+// device by the finalize kernel (same header) and by slots.hip's combine kernels.
 // (A single-launch variant -- device-scope accumulators + arrival ticket -- was measured and rejected: the
 // dependent device-scope atomics cost ~6 us per call, more than the 3-4 us of the second launch.)
-#include "context.h"
+#include "checksum_kernel.h"
 
 #include <atomic>
 
 namespace zr {
-
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-// streaming (read-once) 16-byte load: non-temporal hint, the data is never re-read
-// streaming store of one piece: written once, never read back by this kernel
-typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_stream(uint8_t *p, uint4 v) {
-    u32x4_nt x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<u32x4_nt *>(p));
-}
-
-__device__ __forceinline__ uint4 ld_stream(const uint8_t *p) {
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// first `k` bytes (k in 0..15) of a piece -> 0
-__device__ __forceinline__ uint4 mask_low_bytes(uint4 v, int k) {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int kk = k - 4 * i;                      // bytes of dword i to clear
-        if (kk >= 4) w[i] = 0;
-        else if (kk > 0) w[i] &= 0xffffffffu << (8 * kk);
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// One braid step for one dword: s * x^(8*stride) ^ w, via the bank-replicated LDS tables.
-// lut layout: dword index ((k*256 + e) << 5) + (lane & 31).
-__device__ __forceinline__ uint32_t braid_step(const uint32_t *lut, uint32_t rep, uint32_t s, uint32_t w) {
-    uint32_t r0 = lut[(((s)       & 0xffu) << 5) + rep];
-    uint32_t r1 = lut[(1u << 13) + (((s >> 8)  & 0xffu) << 5) + rep];
-    uint32_t r2 = lut[(2u << 13) + (((s >> 16) & 0xffu) << 5) + rep];
-    uint32_t r3 = lut[(3u << 13) + (((s >> 24)       ) << 5) + rep];
-    return r0 ^ r1 ^ r2 ^ r3 ^ w;
-}
-
-struct StreamArgs {
-    const uint8_t *a0;        // 16-byte aligned
-    uint8_t       *dst0;      // COPY: destination of byte a0[0] (same 16-byte phase as a0), else unused
-    long long      n;         // message bytes
-    long long      body;      // tail_base - a0 (multiple of 16, >= 0)
-    long long      nunits;    // ceil(body / kUnitBytes)
-    int            head;      // buf - a0, 0..15
-    int            tail;      // bytes of the message living in the granule at tail_base
-};
-
-// DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
-template <bool DO_ADLER, bool DO_CRC, bool COPY>
-__global__ __launch_bounds__(kWgThreads)
-void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
-    __shared__ uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
-    __shared__ uint32_t stage[DO_CRC ? 4 * 256 + 256 : 4];   // linear copy of the stride tables + the byte table
-    __shared__ uint32_t red[3][kWgThreads / 64];
-
-    const int t = threadIdx.x;
-    const uint32_t rep = t & 31;
-
-    // contiguous run of units for this workgroup
-    const long long G = gridDim.x, g = blockIdx.x;
-    const long long q = args.nunits / G, r = args.nunits % G;
-    const long long u_lo = g * q + (g < r ? g : r);
-    const long long u_hi = u_lo + q + (g < r ? 1 : 0);
-
-    // byte offset (relative to a0) of this lane's piece in unit u:  body - (nunits-u)*U + 16t
-    long long off = args.body - (args.nunits - u_lo) * (long long)kUnitBytes + (long long)t * kPieceBytes;
-
-    // Main-loop geometry first, so that the first group of HBM loads can be issued BEFORE the tables are built:
-    // their latency then runs under the table build instead of after it.
-    constexpr int UNROLL = 4;
-    const bool head_unit = u_lo < u_hi && u_lo == 0;     // the message's first unit is handled apart (head mask)
-    const long long groups = (u_hi - u_lo - (head_unit ? 1 : 0)) / UNROLL;
-    uint4 bufA[UNROLL], bufB[UNROLL];
-    auto request = [&](uint4 (&buf)[UNROLL], long long at) {
-#pragma unroll
-        for (int j = 0; j < UNROLL; ++j) buf[j] = ld_stream(args.a0 + at + (long long)j * kUnitBytes);
-    };
-    uint32_t group_w0 = 0, group_w1 = 0;
-    if constexpr (DO_CRC) {
-        // tables: HBM/L2 -> LDS once (5 KiB, one dwordx4 per lane), then replicated LDS -> LDS:
-        // 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent dwords
-        uint4 tab = make_uint4(0, 0, 0, 0);
-        if (t < 256) {
-            tab = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
-        } else if (t < 320) {
-            tab = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
-        }
-        // the two digits of this group's end-of-body weight (epilogue, thread 0): fetched now, not on the tail
-        const unsigned long long k_after = (unsigned long long)(args.nunits - u_hi);
-        group_w0 = tabs->unit_pow[0][k_after & 1023u];
-        group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
-        if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
-        if (t < 320) reinterpret_cast<uint4 *>(stage)[t] = tab;
-        __syncthreads();
-        // entry e sits in lut[32 e .. 32 e + 31]: eight lanes write one entry, four replicas (one b128) each
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t v = stage[i * 128 + (t >> 3)];
-            reinterpret_cast<uint4 *>(lut)[i * kWgThreads + t] = make_uint4(v, v, v, v);
-        }
-        __syncthreads();
-    } else {
-        if (groups > 0) request(bufA, off + (head_unit ? (long long)kUnitBytes : 0ll));
-    }
-
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;             // CRC braids
-    uint32_t S1 = 0, SR = 0, SW = 0;                     // Adler: byte sum, prefix-of-sums, in-piece weights
-    unsigned long long accA = 0, accB = 0;               // Adler, reduced mod BASE between batches
-    int batch = 0;
-
-    auto fold_adler = [&](long long off_last) {
-        // B over the batch = sum_k (n - o_k - 16) * A_k + W_k, o_k = piece offset relative to buf.
-        // With pieces one unit apart:  (n - o_last - 16) * S1 + U * SR + SW  (all terms >= 0).
-        unsigned long long lead = (unsigned long long)(args.n - (off_last - args.head) - kPieceBytes);
-        unsigned long long v = (lead % kAdlerBase) * S1 + (unsigned long long)kUnitBytes * SR + SW;
-        accB = (accB + v) % kAdlerBase;
-        accA = (accA + S1) % kAdlerBase;
-        S1 = SR = SW = 0;
-        batch = 0;
-    };
-
-    auto consume = [&](uint4 v) {
-        if constexpr (DO_CRC) {
-            s0 = braid_step(lut, rep, s0, v.x);
-            s1 = braid_step(lut, rep, s1, v.y);
-            s2 = braid_step(lut, rep, s2, v.z);
-            s3 = braid_step(lut, rep, s3, v.w);
-        }
-        if constexpr (DO_ADLER) {
-            uint32_t a = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
-            a = __builtin_amdgcn_sad_u8(v.y, 0u, a);
-            a = __builtin_amdgcn_sad_u8(v.z, 0u, a);
-            a = __builtin_amdgcn_sad_u8(v.w, 0u, a);
-            uint32_t w = __builtin_amdgcn_udot4(v.x, 0x0D0E0F10u, 0u, false);   // weights 16,15,14,13
-            w = __builtin_amdgcn_udot4(v.y, 0x090A0B0Cu, w, false);            // 12..9
-            w = __builtin_amdgcn_udot4(v.z, 0x05060708u, w, false);            // 8..5
-            w = __builtin_amdgcn_udot4(v.w, 0x01020304u, w, false);            // 4..1
-            SR += S1;
-            S1 += a;
-            SW += w;
-        }
-    };
-
-    long long u = u_lo;
-    // first unit of the whole message may be partial (pieces below a0 do not exist) and holds the head mask
-    if (u < u_hi && u == 0) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off >= 0) {
-            v = *reinterpret_cast<const uint4 *>(args.a0 + off);
-            if (off == 0 && args.head) v = mask_low_bytes(v, args.head);
-            if constexpr (COPY) {
-                if (off == 0 && args.head) {
-                    for (int j = args.head; j < 16; ++j) args.dst0[j] = args.a0[j];
-                } else {
-                    *reinterpret_cast<uint4 *>(args.dst0 + off) = v;
-                }
-            }
-        }
-        consume(v);
-        if constexpr (DO_ADLER) { batch = 1; }
-        off += kUnitBytes;
-        ++u;
-    }
-
-    // Main loop, software pipelined with two register buffers (ping-pong, no copies): while group k is
-    // consumed the UNROLL rows of group k+1 are already in flight, so every lane keeps UNROLL..2*UNROLL
-    // dwordx4 loads outstanding (16 waves x 4..8 KiB per CU) and each wait is a counted vmcnt(UNROLL).
-    constexpr int BATCH_MAX = 240;     // u32 bounds: SR <= 4080 * 240*239/2 < 2^27
-    if (groups > 0) {
-        auto retire = [&](uint4 (&buf)[UNROLL]) {
-            if constexpr (COPY) {
-#pragma unroll
-                for (int j = 0; j < UNROLL; ++j)
-                    st_stream(args.dst0 + off + (long long)j * kUnitBytes, buf[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < UNROLL; ++j) consume(buf[j]);
-            off += (long long)UNROLL * kUnitBytes;
-            if constexpr (DO_ADLER) {
-                batch += UNROLL;
-                if (batch >= BATCH_MAX) fold_adler(off - kUnitBytes);
-            }
-        };
-        const long long gstride = (long long)UNROLL * kUnitBytes;
-        long long k = 0;                                   // group 0 is already in flight (issued above)
-        while (k + 2 < groups) {                           // steady state: no conditional loads, counted waits
-            request(bufB, off + gstride);                  // group k+1
-            __builtin_amdgcn_sched_barrier(0);
-            retire(bufA);                                  // group k (off advances by one group)
-            request(bufA, off + gstride);                  // group k+2
-            __builtin_amdgcn_sched_barrier(0);
-            retire(bufB);
-            k += 2;
-        }
-        if (groups - k == 2) {
-            request(bufB, off + gstride);
-            __builtin_amdgcn_sched_barrier(0);
-            retire(bufA);
-            retire(bufB);
-        } else {
-            retire(bufA);
-        }
-        u += groups * UNROLL;
-    }
-    for (; u < u_hi; ++u) {
-        uint4 v = *reinterpret_cast<const uint4 *>(args.a0 + off);
-        if constexpr (COPY) *reinterpret_cast<uint4 *>(args.dst0 + off) = v;
-        consume(v);
-        off += kUnitBytes;
-        if constexpr (DO_ADLER) ++batch;
-    }
-    if constexpr (DO_ADLER) {
-        if (batch) fold_adler(off - kUnitBytes);
-    }
-
-    // ---- workgroup reduction ------------------------------------------------
-    uint32_t pc = 0;
-    if constexpr (DO_CRC) {
-        if (u_hi > u_lo) {
-            // fold the four braids into one word located at the lane's last dword:
-            //   r = ((s0 * x^32 ^ s1) * x^32 ^ s2) * x^32 ^ s3, each x^32 = four byte-table steps (DO1 of
-            //   crc32_braid_p.h:58, the table sits in LDS), then ONE GF(2) multiply by that dword's weight.
-            const uint32_t *bt = stage + 1024;
-            uint32_t r = s0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) r = bt[r & 0xffu] ^ (r >> 8);
-                r ^= c == 0 ? s1 : (c == 1 ? s2 : s3);
-            }
-            // r * (this lane's weight): the 32 partial products weight * x^k come from a table (32 lane-consecutive
-            // loads in flight together) instead of a 32-step shift-and-reduce loop -- that loop was 3.1 of the 7.5 us
-            // a CRC launch costs beyond its streaming time.  Bit 31 of r is the x^0 coefficient.
-            uint32_t part[32];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) pc ^= part[k] & (0u - ((r >> (31 - k)) & 1u));
-        }
-    }
-    uint32_t pa = (uint32_t)accA, pb = (uint32_t)accB;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        if constexpr (DO_CRC) pc ^= __shfl_xor(pc, m, 64);
-        if constexpr (DO_ADLER) {
-            pa += __shfl_xor(pa, m, 64);
-            pb += __shfl_xor(pb, m, 64);
-        }
-    }
-    const int wave = t >> 6;
-    if ((t & 63) == 0) {
-        red[0][wave] = pc;
-        red[1][wave] = pa;     // <= 64 * 65520
-        red[2][wave] = pb;
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t c = 0;
-        unsigned long long a = 0, b = 0;
-        for (int w = 0; w < kWgThreads / 64; ++w) {
-            c ^= red[0][w];
-            a += red[1][w];
-            b += red[2][w];
-        }
-        // Weight this group's CRC to the end of the body: x^(8 * U * units_after), two table digits.  The
-        // common factor x^(8 * tail bytes) is applied once, by the last group.
-        if constexpr (DO_CRC) {
-            const unsigned long long k = (unsigned long long)(args.nunits - u_hi);
-            if (c && k) {
-                c = mulmod(c, group_w0);
-                if (k >> 10) c = mulmod(c, group_w1);
-            }
-        }
-        Partial pt;
-        pt.crc = c;                                   // already weighted to the end of the body
-        pt.a = (uint32_t)(a % kAdlerBase);
-        pt.b = (uint32_t)(b % kAdlerBase);
-        pt.pad = 0;
-        partials[g] = pt;
-    }
-}
-
-struct FinalArgs {
-    const uint8_t *tail_base;   // granule holding the trailing bytes
-    uint8_t       *tail_dst;    // COPY: where those bytes go (else nullptr)
-    long long      n;
-    long long      nunits;
-    int            tail_lo;     // valid bytes of that granule: [tail_lo, tail_hi)
-    int            tail_hi;
-    int            groups;
-    uint32_t       adler_seed;
-    uint32_t       crc_seed_term;   // ~seed * x^(8n), evaluated on the host (a handful of table multiplies)
-    int            do_adler, do_crc;
-};
-
-__global__ __launch_bounds__(256)
-void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const Partial *__restrict__ partials,
-                     uint32_t *__restrict__ out_adler, uint32_t *__restrict__ out_crc) {
-    __shared__ uint32_t red[3][4];
-    const int t = threadIdx.x;
-    const long long G = fa.groups;
-    const int ntail = fa.tail_hi - fa.tail_lo;
-
-    uint32_t c = 0;
-    unsigned long long a = 0, b = 0;
-    for (long long g = t; g < G; g += blockDim.x) {
-        Partial p = partials[g];
-        c ^= p.crc;                                  // weighted to the end of the body by its workgroup
-        a += p.a;
-        b += p.b;
-    }
-    // trailing (< 16) bytes: one lane each; kept apart from the body sum, which still has to be advanced
-    // over them (one multiply, by lane 0 at the end)
-    uint32_t tc = 0;
-    if (t < ntail) {
-        uint32_t byte = fa.tail_base[fa.tail_lo + t];
-        if (fa.tail_dst) fa.tail_dst[fa.tail_lo + t] = (uint8_t)byte;
-        int after = ntail - 1 - t;                  // message bytes behind this one
-        if (fa.do_crc) tc = mulmod(tabs->byte_tab[byte], tabs->pow_tab[after]);
-        a += byte;
-        b += (unsigned long long)byte * (unsigned)(after + 1);
-    }
-    __shared__ uint32_t red_t[4];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        c ^= __shfl_xor(c, m, 64);
-        tc ^= __shfl_xor(tc, m, 64);
-        a += __shfl_xor(a, m, 64);
-        b += __shfl_xor(b, m, 64);
-    }
-    if ((t & 63) == 0) {
-        red_t[t >> 6] = tc;
-        red[0][t >> 6] = c;
-        red[1][t >> 6] = (uint32_t)(a % kAdlerBase);
-        red[2][t >> 6] = (uint32_t)(b % kAdlerBase);
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t cc = red[0][0] ^ red[0][1] ^ red[0][2] ^ red[0][3];
-        unsigned long long A = (unsigned long long)red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        unsigned long long B = (unsigned long long)red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        if (fa.do_adler) {
-            // seed halves are masked, not reduced (adler32_c.c:16-17); s1' = s1 + A, s2' = s2 + n*s1 + B
-            unsigned long long s1 = fa.adler_seed & 0xffffu, s2 = (fa.adler_seed >> 16) & 0xffffu;
-            unsigned long long n_mod = (unsigned long long)fa.n % kAdlerBase;
-            unsigned long long r1 = (s1 + A) % kAdlerBase;
-            unsigned long long r2 = (s2 + n_mod * s1 + B) % kAdlerBase;
-            *out_adler = (uint32_t)(r1 | (r2 << 16));
-        }
-        if (fa.do_crc) {
-            // body advanced over the tail bytes, tail terms, and the seed's image ~seed * x^(8n) (host-evaluated)
-            const uint32_t body = (ntail && cc) ? mulmod(cc, tabs->pow_tab[ntail]) : cc;
-            *out_crc = ~(body ^ red_t[0] ^ red_t[1] ^ red_t[2] ^ red_t[3] ^ fa.crc_seed_term);
-        }
-    }
-}
 
 // ---- host launcher ----------------------------------------------------------
 // CUs the persistent checksum grid leaves alone (zng_rocm_reserve_cus): a workgroup of this kernel fills its CU, so
@@ -406,13 +23,17 @@ static int pick_groups(const Context *c, long long nunits) {
     return (int)g;
 }
 
+void checksum_reset_reserved_cus() { g_reserved_cus.store(0, std::memory_order_relaxed); }
+
 int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const void *d_buf, void *d_dst,
-                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream) {
+                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream,
+                    const uint32_t *d_seed_adler, const uint32_t *d_seed_crc) {
     Context *c = ctx();
     if (!c) {
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
+    DeviceGuard dev;
     if ((!d_buf && len) || (do_adler && !d_out_adler) || (do_crc && !d_out_crc)) {
         set_error("null device pointer");
         return ZNG_ROCM_EINVAL;
@@ -441,6 +62,7 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     sa.nunits = (sa.body + kUnitBytes - 1) / kUnitBytes;
     sa.head = (int)(p - a0);
     sa.tail = (int)((p + len) - tail_base);
+    sa.phase_stamps = nullptr;
 
     FinalArgs fa;
     fa.tail_base = (const uint8_t *)tail_base;
@@ -451,7 +73,10 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     fa.tail_hi = sa.tail;
     if (len == 0) fa.tail_lo = fa.tail_hi = 0;
     fa.adler_seed = adler;
-    fa.crc_seed_term = do_crc ? mulmod(~crc, xpow_bytes(c->host_tables.pow_tab, (uint64_t)len)) : 0u;
+    fa.crc_seed = crc;
+    fa.crc_len_pow = do_crc ? xpow_bytes(c->host_tables.pow_tab, (uint64_t)len) : 0u;
+    fa.adler_seed_ptr = d_seed_adler;
+    fa.crc_seed_ptr = d_seed_crc;
     fa.do_adler = do_adler;
     fa.do_crc = do_crc;
 

@@ -1,9 +1,11 @@
 // context.h -- process-global device context of the arch/rocm backend:
-// constant tables in HBM, per-stream workspaces, pinned staging, error state.
+// constant tables in HBM, per-stream workspaces and scratch, bounded staging, error state.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+
+#include <mutex>
 
 #include "../../include/zng_rocm.h"
 #include "gf2.h"
@@ -26,6 +28,8 @@ struct DeviceTables {
     uint32_t unit_pow[2][1024];          // x^(8 * kUnitBytes * d * 1024^i): weight of "d units later", two 10-bit digits
     uint32_t lane_pow[32][kWgThreads];   // lane_weight[t][3] * x^k, k = 0..31 (k-major: lane-consecutive loads): the 32
                                          //   partial products of the epilogue's per-lane GF(2) multiply, precomputed
+    uint32_t x32_tab[4][256];            // byte k of a word -> times x^32 (the fold of one braid into the next, one
+                                         //   LDS latency instead of four dependent byte-table steps)
 };
 
 struct Partial {            // one per workgroup, written by the streaming kernel
@@ -35,18 +39,47 @@ struct Partial {            // one per workgroup, written by the streaming kerne
     uint32_t pad;
 };
 
+// Growable per-stream scratch buffers of the stream-level entry points.  They are keyed by HIP stream: work on one
+// stream is ordered, so a buffer is never under a running kernel of ANOTHER caller (SURVEY.md 8b "Threading":
+// distinct zlib-ng streams are used concurrently from different host threads).
+enum ScratchSlot {
+    kScrQuickJobs = 0,      // device: StreamJobDev[] of zng_rocm_deflate_quick_dev
+    kScrQuickJobsHost,      // pinned host mirror of the same (async H2D source)
+    kScrQuickSel,           // device: selectors of the level-1 class
+    kScrDynJobs,            // device: SegJob[] of zng_rocm_deflate_dev
+    kScrDynJobsHost,        // pinned
+    kScrDynSel,             // device: one 32-bit selector per input byte (level-6 class)
+    kScrDynSlots,           // device: per-segment output slots
+    kScrDynSegLen,          // device: u32 per segment
+    kScrDynSegLenHost,      // pinned
+    kScrDynDstOff,          // device: u64 per segment
+    kScrDynDstOffHost,      // pinned
+    kScrInflate,            // device: tokens | segs | literals | symbols of the one-shot inflate
+    kScrInflateHost,        // pinned token staging of the batched inflate
+    kScrCount
+};
+
+struct Scratch {
+    void  *p;
+    size_t cap;
+    bool   host;            // pinned host memory (hipHostMalloc) instead of device memory
+};
+
 struct Workspace {          // one per HIP stream
     Partial  *partials;     // kMaxGroups entries
-    uint32_t *acc;          // {crc xor, adler A sum, adler B sum, ticket}: device-scope accumulators, zero between calls
-    uint32_t *result;       // 2 x u32 scratch result (device)
+    uint32_t *acc;          // spare device words (zero between calls)
+    uint32_t *result;       // 2 x u32 scratch result (device) + 2 x u32 chained seed
     uint32_t *pinned;       // 2 x u32 host-pinned mirror
-    uint8_t  *stage;        // device staging for host-pointer slots
+    uint8_t  *stage;        // device staging chunk(s) for host-pointer slots, bounded (kStageChunk)
     size_t    stage_bytes;
-    uint8_t  *pinned_stage; // pinned bounce buffer for H2D
-    size_t    pinned_bytes;
+    Scratch   scratch[kScrCount];
+    hipEvent_t host_done;   // recorded behind the last async copy that READS a pinned scratch buffer
+    bool       host_busy;   // such a copy may still be in flight: synchronise host_done before rewriting
+    std::mutex mu;          // host-side use of this workspace (growth, pinned tables): one enqueue at a time per stream
 };
 
 struct Context {
+    uint64_t      generation;   // distinguishes this context from one created after a zng_rocm_shutdown()
     int           device;
     int           cus;
     int           lds_bytes;
@@ -70,8 +103,31 @@ void set_error(const char *fmt, ...);
 void trace_mark(hipStream_t s, bool begin);
 
 Context   *ctx();                          // nullptr until zng_rocm_init succeeded
-Workspace *workspace_for(hipStream_t s);   // lazily created, nullptr on failure
+Workspace *workspace_for(hipStream_t s);   // lazily created on the context's device, nullptr on failure
 int        ensure_stage(Workspace *ws, size_t bytes);
+// scratch slot `slot` of the workspace with at least `bytes` (contents are NOT preserved when it grows)
+int        scratch_reserve(Workspace *ws, int slot, size_t bytes, bool pinned_host, void **out);
+// pinned tables are rewritten by the host: wait until the last async copy that read them has finished
+int        host_tables_acquire(Workspace *ws);
+int        host_tables_release(Workspace *ws, hipStream_t s);      // record host_done behind the copies just issued
 [[noreturn]] void die(const char *what);   // loud failure for slots without an error channel
+
+// HIP's current device is per host thread (default 0): every entry point that allocates or launches runs under one
+// of these, so that a call from a thread that never selected the context's device still lands on it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    DeviceGuard();
+    ~DeviceGuard();
+};
+
+void checksum_reset_reserved_cus();        // checksum.hip
+
+// checksum.hip: one streaming pass (+ finalize) over device-resident bytes.  d_dst != nullptr = fold_copy.  When a
+// d_seed_* pointer is given, that checksum's seed is read ON THE DEVICE from it at finalize time (the word an earlier
+// launch on the same stream wrote) instead of from the scalar argument.
+int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const void *d_buf, void *d_dst,
+                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream,
+                    const uint32_t *d_seed_adler = nullptr, const uint32_t *d_seed_crc = nullptr);
 
 }  // namespace zr

@@ -25,7 +25,6 @@
 #include "deflate_chain.h"
 
 #include <mutex>
-#include <vector>
 
 namespace zr {
 
@@ -585,18 +584,40 @@ void gather_segments_kernel(const SegJob *__restrict__ jobs, const uint32_t *__r
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = job.out[i];
 }
 
-struct DynScratch {
-    SegJob   *d_jobs = nullptr;
-    size_t    job_cap = 0;
-    uint32_t *d_sel = nullptr;
-    size_t    sel_cap = 0;
-    uint8_t  *d_slots = nullptr;
-    size_t    slot_cap = 0;
-    uint32_t *d_seg_len = nullptr;
-    uint64_t *d_dst_off = nullptr;
-};
-static DynScratch g_dyn;
-static std::mutex g_scratch_mu;      // the scratch buffers are process-wide: one deflate call at a time
+// Level 0: deflate_stored (deflate_stored.c:27-186) for a complete, device-resident plaintext and an output buffer
+// that holds everything -- the case in which the reference copies straight from next_in to next_out in stored blocks
+// of MAX_STORED = 65535 bytes (deflate_stored.c:46-95), the last one carrying BFINAL.  A byte copy with a 5-byte
+// header (RFC 1951 3.2.4) in front of every 65535 bytes: 2N of HBM traffic, 16 bytes per lane.
+constexpr uint32_t kMaxStored = 65535u;
+
+__global__ __launch_bounds__(256)
+void stored_kernel(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ out) {
+    const size_t nblk = n ? (n + kMaxStored - 1) / kMaxStored : 1;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = gid; k < nblk; k += gsz) {
+        const size_t left = n - k * kMaxStored;
+        const uint32_t ln = left < kMaxStored ? (uint32_t)left : kMaxStored;
+        uint8_t *h = out + k * (kMaxStored + 5u);
+        h[0] = k + 1 == nblk ? 1 : 0;                               // BFINAL, BTYPE = 00, padding bits
+        h[1] = (uint8_t)ln;
+        h[2] = (uint8_t)(ln >> 8);
+        h[3] = (uint8_t)~ln;
+        h[4] = (uint8_t)(~ln >> 8);
+    }
+    // payload: lane i moves input bytes [16 i, 16 i + 16); a piece that straddles a block border is split by bytes
+    const size_t npiece = (n + 15) / 16;
+    for (size_t i = gid; i < npiece; i += gsz) {
+        const size_t p = i * 16;
+        const size_t blk = p / kMaxStored;
+        uint8_t *dst = out + p + 5u * (blk + 1);
+        if (p + 16 <= n && (p + 15) / kMaxStored == blk) {
+            const u32x4_unaligned v = load_u128(in + p);
+            *reinterpret_cast<u32x4_unaligned *>(dst) = v;
+        } else {
+            for (size_t q = p; q < p + 16 && q < n; ++q) out[q + 5u * (q / kMaxStored + 1)] = in[q];
+        }
+    }
+}
 
 static inline size_t seg_slot_bytes(uint32_t n) {
     // <= 9 bits per literal for an almost flat alphabet, + header (< 400 bytes) + trailer; 4-byte aligned
@@ -611,6 +632,7 @@ extern "C" {
 
 size_t zng_rocm_deflate_bound(size_t source_len) {
     const size_t nseg = source_len ? (source_len + kSegBytesMin - 1) / kSegBytesMin : 1;     // the most there can be
+    // covers level 0 too: 5 bytes per 65535 (deflate_stored) is far below the n/8 term
     return source_len + source_len / 8 + nseg * 1032 + 16;
 }
 
@@ -621,8 +643,8 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         return ZNG_ROCM_ENODEV;
     }
     if (!out_len || !d_out || (!d_in && in_len)) return ZNG_ROCM_EINVAL;
-    if (level < 2 || level > 9) {
-        set_error("zng_rocm_deflate_dev implements the chain-walking levels (2..9); level 1 is zng_rocm_deflate_quick_dev");
+    if (level < 0 || level > 9) {
+        set_error("level %d is outside 0..9", level);
         return ZNG_ROCM_EINVAL;
     }
     if (in_len >= (1ull << 32) - kSegBytes) {
@@ -633,20 +655,54 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         set_error("out_cap below zng_rocm_deflate_bound()");
         return -5;
     }
-    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
     hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dev;
+    // scratch is keyed by the caller's HIP stream (context.h): concurrent callers on different streams share nothing
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
     // max_chain_length per level, deflate.c:142-168
-    static const uint32_t chains[10] = {0, 4, 4, 6, 24, 32, 128, 256, 1024, 4096};
+    if (level == 0) {                                               // deflate_stored: no scratch, no host round trip
+        const size_t nblk = in_len ? (in_len + kMaxStored - 1) / kMaxStored : 1;
+        const size_t total0 = in_len + 5 * nblk;
+        if (total0 > out_cap) {
+            set_error("stored size %llu exceeds out_cap", (unsigned long long)total0);
+            return -5;
+        }
+        const size_t pieces = (in_len + 15) / 16 + nblk;
+        unsigned grid = (unsigned)((pieces + 255) / 256);
+        if (grid > 65536u) grid = 65536u;
+        if (grid == 0) grid = 1;
+        trace_mark(st, true);
+        hipLaunchKernelGGL(stored_kernel, dim3(grid), dim3(256), 0, st, d_in, in_len, d_out);
+        trace_mark(st, false);
+        ZR_HIP(hipGetLastError());
+        ZR_HIP(hipStreamSynchronize(st));
+        *out_len = total0;
+        return ZNG_ROCM_OK;
+    }
+    // level 1 here = deflate_quick's matcher (one probe of the chain head, deflate_quick.c:89-97) run segment-parallel
+    // on ONE large stream; the many-stream form of level 1 is zng_rocm_deflate_quick_dev
+    static const uint32_t chains[10] = {0, 1, 4, 6, 24, 32, 128, 256, 1024, 4096};
     uint32_t max_chain = chains[level];
     if (max_chain > 256) max_chain = 256;
     static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};     // good_match per level, deflate.c:142-168
     const uint32_t good_match = goods[level];
 
-    int32_t dev_info[4] = {256, 0, 64, 8};
-    (void)zng_rocm_device_info(dev_info);
-    const size_t seg_bytes = segment_bytes(in_len, dev_info[0]);
+    const size_t seg_bytes = segment_bytes(in_len, ctx()->cus);
     const size_t nseg = in_len ? (in_len + seg_bytes - 1) / seg_bytes : 1;
-    std::vector<SegJob> jobs(nseg);
+    SegJob *d_jobs = nullptr, *jobs = nullptr;
+    uint32_t *d_sel = nullptr, *d_seg_len = nullptr, *lens = nullptr;
+    uint64_t *d_dst_off = nullptr, *offs = nullptr;
+    uint8_t *d_slots = nullptr;
+    if (int rc = host_tables_acquire(ws)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSegLenHost, nseg * sizeof(uint32_t), true, (void **)&lens)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynDstOffHost, nseg * sizeof(uint64_t), true, (void **)&offs)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * sizeof(uint32_t), false, (void **)&d_seg_len)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynDstOff, nseg * sizeof(uint64_t), false, (void **)&d_dst_off)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSel, (in_len + 1024) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
     size_t slot_total = 0;
     for (size_t i = 0; i < nseg; ++i) {
         const uint32_t a = (uint32_t)(i * seg_bytes);
@@ -660,45 +716,21 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         jobs[i].out = (uint8_t *)slot_total;          // offset for now
         slot_total += jobs[i].out_cap;
     }
-    if (nseg > g_dyn.job_cap) {
-        if (g_dyn.d_jobs) (void)hipFree(g_dyn.d_jobs);
-        if (g_dyn.d_seg_len) (void)hipFree(g_dyn.d_seg_len);
-        if (g_dyn.d_dst_off) (void)hipFree(g_dyn.d_dst_off);
-        g_dyn.job_cap = 0;
-        ZR_HIP(hipMalloc(&g_dyn.d_jobs, nseg * sizeof(SegJob)));
-        ZR_HIP(hipMalloc(&g_dyn.d_seg_len, nseg * sizeof(uint32_t)));
-        ZR_HIP(hipMalloc(&g_dyn.d_dst_off, nseg * sizeof(uint64_t)));
-        g_dyn.job_cap = nseg;
-    }
-    if (in_len + 1024 > g_dyn.sel_cap) {
-        if (g_dyn.d_sel) (void)hipFree(g_dyn.d_sel);
-        g_dyn.sel_cap = 0;
-        ZR_HIP(hipMalloc(&g_dyn.d_sel, (in_len + 1024) * sizeof(uint32_t)));
-        g_dyn.sel_cap = in_len + 1024;
-    }
-    if (slot_total > g_dyn.slot_cap) {
-        if (g_dyn.d_slots) (void)hipFree(g_dyn.d_slots);
-        g_dyn.slot_cap = 0;
-        ZR_HIP(hipMalloc(&g_dyn.d_slots, slot_total));
-        g_dyn.slot_cap = slot_total;
-    }
-    for (size_t i = 0; i < nseg; ++i) jobs[i].out = g_dyn.d_slots + (size_t)jobs[i].out;
-    ZR_HIP(hipMemcpyAsync(g_dyn.d_jobs, jobs.data(), nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
+    if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
+    for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
+    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
 
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, g_dyn.d_jobs, g_dyn.d_sel, max_chain,
+    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, d_jobs, d_sel, max_chain,
                        good_match);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs, g_dyn.d_sel,
-                       g_dyn.d_seg_len);
+    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_sel, d_seg_len);
     ZR_HIP(hipGetLastError());
 
-    // segment lengths -> offsets (host; the one synchronisation of this entry point)
-    std::vector<uint32_t> lens(nseg);
-    ZR_HIP(hipMemcpyAsync(lens.data(), g_dyn.d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // segment lengths -> offsets (host; the one mid-call synchronisation of this entry point)
+    ZR_HIP(hipMemcpyAsync(lens, d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
-    std::vector<uint64_t> offs(nseg);
     uint64_t total = 0;
     for (size_t i = 0; i < nseg; ++i) {
         offs[i] = total;
@@ -708,9 +740,9 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         set_error("compressed size %llu exceeds out_cap", (unsigned long long)total);
         return -5;
     }
-    ZR_HIP(hipMemcpyAsync(g_dyn.d_dst_off, offs.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, st, g_dyn.d_jobs,
-                       g_dyn.d_seg_len, g_dyn.d_dst_off, d_out);
+    ZR_HIP(hipMemcpyAsync(d_dst_off, offs, nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off,
+                       d_out);
     ZR_HIP(hipGetLastError());
     ZR_HIP(hipStreamSynchronize(st));
     *out_len = (size_t)total;

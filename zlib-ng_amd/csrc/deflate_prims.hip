@@ -281,6 +281,7 @@ extern "C" {
 
 int zng_rocm_slide_hash_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || nstreams > 65535) return ZNG_ROCM_EINVAL;
     // (65536 + 32768) / 8 = 12288 vectors per stream = 48 blocks of 256 lanes
@@ -292,6 +293,7 @@ int zng_rocm_slide_hash_dev(const zng_rocm_deflate_view *d_views, size_t nstream
 int zng_rocm_compare256_dev(const uint8_t *d_base, const uint64_t *d_off0, const uint64_t *d_off1, size_t npairs,
                             uint32_t *d_len, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!npairs) return ZNG_ROCM_OK;
     if (!d_base || !d_off0 || !d_off1 || !d_len) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(compare256_kernel, dim3(waves_to_blocks(npairs)), dim3(256), 0, (hipStream_t)stream, d_base,
@@ -302,6 +304,7 @@ int zng_rocm_compare256_dev(const uint8_t *d_base, const uint64_t *d_off0, const
 
 int zng_rocm_update_hash_dev(const uint32_t *d_val, size_t n, uint32_t *d_hash, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!n) return ZNG_ROCM_OK;
     if (!d_val || !d_hash) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(update_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_val,
@@ -312,6 +315,7 @@ int zng_rocm_update_hash_dev(const uint32_t *d_val, size_t n, uint32_t *d_hash, 
 
 int zng_rocm_update_hash_roll_dev(const uint32_t *d_h, const uint32_t *d_val, size_t n, uint32_t *d_hash, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!n) return ZNG_ROCM_OK;
     if (!d_h || !d_val || !d_hash) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(update_hash_roll_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -323,6 +327,7 @@ int zng_rocm_update_hash_roll_dev(const uint32_t *d_h, const uint32_t *d_val, si
 int zng_rocm_quick_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
                                           uint32_t *d_ins_h, uint16_t *d_head_out, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_str || !d_ins_h || !d_head_out) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(quick_insert_roll_kernel, dim3((unsigned)((nstreams + 255) / 256)), dim3(256), 0,
@@ -334,6 +339,7 @@ int zng_rocm_quick_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, 
 int zng_rocm_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
                                     const uint32_t *d_count, uint32_t *d_ins_h, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_str || !d_count || !d_ins_h) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(insert_string_roll_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
@@ -345,6 +351,7 @@ int zng_rocm_insert_string_roll_dev(const zng_rocm_deflate_view *d_views, size_t
 int zng_rocm_quick_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
                                      uint16_t *d_head_out, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_str || !d_head_out) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(quick_insert_kernel, dim3((unsigned)((nstreams + 255) / 256)), dim3(256), 0,
@@ -356,6 +363,7 @@ int zng_rocm_quick_insert_string_dev(const zng_rocm_deflate_view *d_views, size_
 int zng_rocm_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint32_t *d_str,
                                const uint32_t *d_count, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_str || !d_count) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(insert_string_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
@@ -367,6 +375,7 @@ int zng_rocm_insert_string_dev(const zng_rocm_deflate_view *d_views, size_t nstr
 int zng_rocm_longest_match_dev(const zng_rocm_deflate_view *d_views, size_t nstreams, const uint16_t *d_cur_match,
                                uint32_t *d_len_out, uint32_t *d_match_start_out, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_cur_match || !d_len_out || !d_match_start_out) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(longest_match_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
@@ -379,6 +388,7 @@ int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t
                                     const uint16_t *d_cur_match, uint32_t *d_len_out, uint32_t *d_match_start_out,
                                     void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!nstreams) return ZNG_ROCM_OK;
     if (!d_views || !d_cur_match || !d_len_out || !d_match_start_out) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(longest_match_slow_kernel, dim3(waves_to_blocks(nstreams)), dim3(256), 0, (hipStream_t)stream,
@@ -390,6 +400,7 @@ int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t
 int zng_rocm_chunkmemset_safe_dev(uint8_t *d_base, const uint64_t *d_out_off, const uint64_t *d_from_off,
                                   const uint32_t *d_len, const uint32_t *d_left, size_t ncopies, void *stream) {
     if (int rc = need_ctx()) return rc;
+    DeviceGuard dev;
     if (!ncopies) return ZNG_ROCM_OK;
     if (!d_base || !d_out_off || !d_from_off || !d_len || !d_left) return ZNG_ROCM_EINVAL;
     hipLaunchKernelGGL(chunkmemset_kernel, dim3((unsigned)((ncopies + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_base,

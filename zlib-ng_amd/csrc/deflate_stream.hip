@@ -22,7 +22,6 @@
 
 #include <stdlib.h>
 #include <mutex>
-#include <vector>
 
 namespace zr {
 
@@ -253,16 +252,6 @@ void emit_static_kernel(const StreamJobDev *__restrict__ jobs, const uint32_t *_
     }
 }
 
-struct DeflateScratch {
-    StreamJobDev *d_jobs = nullptr;
-    std::vector<StreamJobDev> h_jobs; // pageable on purpose: hipMemcpyAsync stages it before returning
-    size_t        job_cap = 0;
-    uint32_t     *d_sel = nullptr;
-    size_t        sel_cap = 0;
-};
-static DeflateScratch g_ds;
-static std::mutex g_scratch_mu;      // the scratch buffers are process-wide: one deflate call at a time
-
 }  // namespace zr
 
 using namespace zr;
@@ -284,15 +273,18 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     if (!njobs) return ZNG_ROCM_OK;
     if (!jobs || !d_results) return ZNG_ROCM_EINVAL;
-    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
     hipStream_t st = (hipStream_t)stream;
-    if (njobs > g_ds.job_cap) {
-        if (g_ds.d_jobs) (void)hipFree(g_ds.d_jobs);
-        g_ds.job_cap = 0;
-        ZR_HIP(hipMalloc(&g_ds.d_jobs, njobs * sizeof(StreamJobDev)));
-        g_ds.job_cap = njobs;
-    }
-    g_ds.h_jobs.resize(njobs);
+    DeviceGuard dev;
+    // All scratch of this entry point belongs to the caller's HIP stream: two callers on two streams (two pigz-style
+    // host threads) never share a buffer, and calls on one stream are ordered by the stream itself.
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    StreamJobDev *d_jobs = nullptr, *h_jobs = nullptr;
+    if (int rc = scratch_reserve(ws, kScrQuickJobs, njobs * sizeof(StreamJobDev), false, (void **)&d_jobs)) return rc;
+    // the previous call's table may still be on its way to the device: wait for that copy, not for its kernels
+    if (int rc = host_tables_acquire(ws)) return rc;
+    if (int rc = scratch_reserve(ws, kScrQuickJobsHost, njobs * sizeof(StreamJobDev), true, (void **)&h_jobs)) return rc;
     uint64_t total = 0;
     for (size_t i = 0; i < njobs; ++i) {
         const zng_rocm_stream_job &j = jobs[i];
@@ -302,22 +294,18 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
                       "zng_rocm_deflate_quick_bound(in_len)", i);
             return ZNG_ROCM_EINVAL;
         }
-        g_ds.h_jobs[i] = StreamJobDev{j.in, j.out, j.in_len, j.out_cap, total};
+        h_jobs[i] = StreamJobDev{j.in, j.out, j.in_len, j.out_cap, total};
         total += ((uint64_t)j.in_len + 3u) & ~3ull;           // selector regions stay 16-byte aligned
     }
-    if (total > g_ds.sel_cap) {
-        if (g_ds.d_sel) (void)hipFree(g_ds.d_sel);
-        g_ds.sel_cap = 0;
-        ZR_HIP(hipMalloc(&g_ds.d_sel, (total + 1024) * sizeof(uint32_t)));
-        g_ds.sel_cap = total + 1024;
-    }
-    ZR_HIP(hipMemcpyAsync(g_ds.d_jobs, g_ds.h_jobs.data(), njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
+    uint32_t *d_sel = nullptr;
+    if (int rc = scratch_reserve(ws, kScrQuickSel, (total + 1024) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
+    ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
+    if (int rc = host_tables_release(ws, st)) return rc;
     trace_mark(st, true);
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3((unsigned)njobs), dim3(256), 0, st, d_jobs, d_sel);
     trace_mark(st, false);
     ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, g_ds.d_jobs, g_ds.d_sel,
-                       d_results);
+    hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, d_jobs, d_sel, d_results);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }

@@ -219,6 +219,7 @@ int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
+    DeviceGuard dev;
     (void)ntokens;
     if (out_len == 0 || nsegs == 0) return ZNG_ROCM_OK;
     if (!d_tokens || !d_segs || !d_symbols || !d_out) return ZNG_ROCM_EINVAL;
@@ -256,6 +257,7 @@ int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, 
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
+    DeviceGuard dev;
     hipStream_t st = (hipStream_t)stream;
     zng_rocm_inflate_tokens tk;
     int status = zng_rocm_inflate_tokens_decode(src, src_len, &tk);

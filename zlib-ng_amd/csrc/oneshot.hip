@@ -21,10 +21,7 @@ extern "C" int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8
 
 namespace zr {
 
-int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const void *d_buf, void *d_dst,
-                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream);
-
-enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
+enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_STREAM_ERROR_ = -2, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
 
 // adler32 / crc32 of a device buffer, synchronously (the one-shot front ends return a status)
 static int device_checks(const uint8_t *d_buf, size_t len, hipStream_t st, uint32_t out[2]) {
@@ -56,9 +53,13 @@ int zng_rocm_compress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *d_src
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
+    DeviceGuard dev;
     if (!d_dst || !dst_len || (!d_src && src_len) || format < 0 || format > 2) return ZNG_ROCM_EINVAL;
-    if (level == -1) level = 6;                                   // Z_DEFAULT_COMPRESSION
-    if (level < 2) level = 2;                                     // the single-stream kernel is the chain class
+    if (level == -1) level = 6;                                   // Z_DEFAULT_COMPRESSION (deflate.c:296)
+    if (level < 0 || level > 9) {                                 // deflateInit2: Z_STREAM_ERROR (deflate.c:318-320)
+        set_error("level %d is outside -1..9", level);
+        return Z_STREAM_ERROR_;
+    }
     hipStream_t st = (hipStream_t)stream;
     const size_t head = format == 1 ? 2 : format == 2 ? 10 : 0;
     const size_t trail = format == 1 ? 4 : format == 2 ? 8 : 0;
@@ -85,8 +86,8 @@ int zng_rocm_compress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *d_src
         h[1] = (uint8_t)header;
         t[0] = (uint8_t)(chk[0] >> 24); t[1] = (uint8_t)(chk[0] >> 16); t[2] = (uint8_t)(chk[0] >> 8); t[3] = (uint8_t)chk[0];
     } else if (format == 2) {
-        // deflate.c:902-920: minimal gzip header (no name/extra/comment), XFL by level, OS 3 (Unix)
-        const uint8_t gh[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, (uint8_t)(level == 9 ? 2 : level == 1 ? 4 : 0), 3};
+        // deflate.c:902-916: minimal gzip header (no name/extra/comment), XFL by level (:913-914), OS 3 (Unix)
+        const uint8_t gh[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, (uint8_t)(level == 9 ? 2 : level < 2 ? 4 : 0), 3};
         memcpy(h, gh, 10);
         for (int i = 0; i < 4; ++i) {
             t[i] = (uint8_t)(chk[1] >> (8 * i));                   // CRC32 then ISIZE, little endian (deflate.c:1091-1096)
@@ -106,6 +107,7 @@ int zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *src
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
+    DeviceGuard dev;
     if (!dst_len || !src_len || (!src && *src_len) || format < 0 || format > 2) return ZNG_ROCM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t n = *src_len;
@@ -138,8 +140,17 @@ int zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *src
                 ++pos;
             }
         }
-        if (flags & 2) pos += 2;                                 // FHCRC (not verified here)
         if (pos > n) { set_error("input ended inside the gzip header"); return Z_DATA_ERROR_; }
+        if (flags & 2) {                                         // FHCRC: low 16 bits of the CRC-32 of the header so far
+            if (pos + 2 > n) { set_error("input ended inside the gzip header"); return Z_DATA_ERROR_; }
+            uint32_t c = 0xffffffffu;                            // inflate.c:686-692 (state->check over the header)
+            const uint32_t *bt = ctx()->host_tables.byte_tab;
+            for (size_t i = 0; i < pos; ++i) c = bt[(c ^ src[i]) & 0xffu] ^ (c >> 8);
+            c = ~c;
+            const unsigned want = src[pos] | ((unsigned)src[pos + 1] << 8);
+            if (want != (c & 0xffffu)) { set_error("header crc mismatch"); return Z_DATA_ERROR_; }
+            pos += 2;
+        }
     }
     const size_t trail = format == 1 ? 4 : format == 2 ? 8 : 0;
     uint64_t got = 0;

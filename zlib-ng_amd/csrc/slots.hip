@@ -13,54 +13,93 @@
 
 #include <string.h>
 
+#include <mutex>
+
 namespace zr {
 
-int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const void *d_buf, void *d_dst,
-                    size_t len, uint32_t *d_out_adler, uint32_t *d_out_crc, hipStream_t stream);
-
-static thread_local hipStream_t t_stream = nullptr;
-
-static hipStream_t slot_stream() {
-    if (!t_stream) {
-        if (!ctx()) {
-            // a functable slot may be the first thing a process calls (functable.c:269-360 lazy init)
-            if (zng_rocm_init(-1) != ZNG_ROCM_OK) die("zng_rocm_init");
+// ---- the calling thread's HIP stream -------------------------------------------
+// Per host thread, so independent zlib-ng streams used from different threads do not serialise (zlib-ng.h.in:157-159).
+// The holder releases the stream and its workspace when the thread ends, and re-creates it when the context it was
+// made under is gone (zng_rocm_shutdown followed by a new zng_rocm_init, possibly on another device).
+struct SlotStream {
+    hipStream_t stream = nullptr;
+    uint64_t    generation = 0;
+    ~SlotStream() { drop(); }
+    void drop() {
+        Context *c = ctx();
+        if (stream && c && c->generation == generation) {
+            (void)zng_rocm_stream_release(stream);
+            DeviceGuard dev;
+            (void)hipStreamDestroy(stream);
         }
-        if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess) {
-            set_error("hipStreamCreate failed");
-            die("slot stream");
-        }
+        stream = nullptr;            // a stream of a context that was shut down died with its device state
     }
-    return t_stream;
+};
+static thread_local SlotStream t_slot;
+
+static int slot_stream(hipStream_t *out) {
+    Context *c = ctx();
+    if (!c) {
+        // a functable slot may be the first thing a process calls (functable.c:269-360 lazy init)
+        int rc = zng_rocm_init(-1);
+        if (rc != ZNG_ROCM_OK) return rc;
+        c = ctx();
+    }
+    if (!t_slot.stream || t_slot.generation != c->generation) {
+        t_slot.drop();
+        DeviceGuard dev;
+        ZR_HIP(hipStreamCreateWithFlags(&t_slot.stream, hipStreamNonBlocking));
+        t_slot.generation = c->generation;
+    }
+    *out = t_slot.stream;
+    return ZNG_ROCM_OK;
 }
 
-// host bytes -> device staging -> kernel -> two result words
-static void run_host(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const uint8_t *src, uint8_t *dst,
-                     size_t len, uint32_t out[2]) {
-    hipStream_t st = slot_stream();
+// Host bytes -> bounded device staging -> kernel -> two result words.
+// The message goes through ONE device chunk of at most kStageChunk bytes, however long it is: copy a chunk, run the
+// streaming pass over it with the seed taken ON THE DEVICE from the previous chunk's result (chunks of one call are
+// ordered on the thread's stream, so the seed chains without a host round trip), copy the next.  The pageable copy
+// is staged by the HIP runtime through its own pinned buffers; the kernel of a 16 MiB chunk takes ~10 us against
+// ~300 us of PCIe time, so nothing is gained by a second chunk in flight.  One synchronisation per call.
+constexpr size_t kStageChunk = 16u << 20;
+
+static int run_host(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const uint8_t *src, uint8_t *dst,
+                    size_t len, uint32_t out[2]) {
+    hipStream_t st;
+    if (int rc = slot_stream(&st)) return rc;
+    DeviceGuard dev;
     Workspace *ws = workspace_for(st);
-    if (!ws) die("workspace");
-    if (ensure_stage(ws, (dst ? 2 : 1) * (len + 64)) != ZNG_ROCM_OK) die("staging buffer");
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    const size_t chunk = len < kStageChunk ? len : kStageChunk;
+    const size_t half = (chunk + 63) & ~(size_t)15;                  // src chunk | dst chunk, same 16-byte phase
+    if (int rc = ensure_stage(ws, (dst ? 2 : 1) * half + 64)) return rc;
     uint8_t *d_src = ws->stage;
-    uint8_t *d_dst = dst ? ws->stage + ((len + 63) & ~(size_t)15) + 16 : nullptr;
-    if (len && hipMemcpyAsync(d_src, src, len, hipMemcpyHostToDevice, st) != hipSuccess) {
-        set_error("H2D copy failed");
-        die("hipMemcpyAsync");
-    }
-    if (launch_checksum(do_adler, do_crc, adler, crc, d_src, len ? d_dst : nullptr, len, ws->result, ws->result + 1,
-                        st) != ZNG_ROCM_OK)
-        die("checksum launch");
-    if (dst && len && hipMemcpyAsync(dst, d_dst, len, hipMemcpyDeviceToHost, st) != hipSuccess) {
-        set_error("D2H copy failed");
-        die("hipMemcpyAsync");
-    }
-    if (hipMemcpyAsync(ws->pinned, ws->result, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        set_error("result readback failed: %s", hipGetErrorString(hipGetLastError()));
-        die("hipStreamSynchronize");
-    }
+    uint8_t *d_dst = dst ? ws->stage + half + 16 : nullptr;
+    uint32_t *res = ws->result;                                      // [0..1] result, [2..3] the chained seed
+    size_t done = 0;
+    bool first = true;
+    do {
+        const size_t m = len - done < kStageChunk ? len - done : kStageChunk;
+        if (m) ZR_HIP(hipMemcpyAsync(d_src, src + done, m, hipMemcpyHostToDevice, st));
+        if (!first) ZR_HIP(hipMemcpyAsync(res + 2, res, 8, hipMemcpyDeviceToDevice, st));
+        if (int rc = launch_checksum(do_adler, do_crc, adler, crc, d_src, m ? d_dst : nullptr, m, res, res + 1, st,
+                                     first ? nullptr : res + 2, first ? nullptr : res + 3))
+            return rc;
+        if (dst && m) ZR_HIP(hipMemcpyAsync(dst + done, d_dst, m, hipMemcpyDeviceToHost, st));
+        done += m;
+        first = false;
+    } while (done < len);
+    ZR_HIP(hipMemcpyAsync(ws->pinned, res, 8, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipStreamSynchronize(st));
     out[0] = ws->pinned[0];
     out[1] = ws->pinned[1];
+    return ZNG_ROCM_OK;
+}
+
+static void run_host_or_die(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, const uint8_t *src, uint8_t *dst,
+                            size_t len, uint32_t out[2], const char *slot) {
+    if (run_host(do_adler, do_crc, adler, crc, src, dst, len, out) != ZNG_ROCM_OK) die(slot);
 }
 
 // ---- combine kernels ---------------------------------------------------------
@@ -154,6 +193,7 @@ static int launch_combine(const uint32_t *d_checks, const uint64_t *d_lens, size
         return ZNG_ROCM_ENODEV;
     }
     if (!d_out || (count && (!d_checks || !d_lens))) return ZNG_ROCM_EINVAL;
+    DeviceGuard dev;
     hipLaunchKernelGGL((combine_kernel<IS_CRC>), dim3(1), dim3(1024), 0, stream, d_checks, d_lens, (long long)count,
                        check_stride, len_stride, c->tables, d_out);
     ZR_HIP(hipGetLastError());
@@ -161,15 +201,14 @@ static int launch_combine(const uint32_t *d_checks, const uint64_t *d_lens, size
 }
 
 // host-side polynomial helpers for the scalar combine API
-static uint32_t host_x2n_table[32];
-static bool host_x2n_ready = false;
+static uint32_t host_x2n_table[32];          // x2n_table of crc32_braid_tbl.h:9437-9444, built as tools/makecrct.c:75-79 does
+static std::once_flag host_x2n_once;
 static uint32_t host_x2nmodp(int64_t n, unsigned k) {
-    if (!host_x2n_ready) {
+    std::call_once(host_x2n_once, [] {
         uint32_t p = 0x40000000u;
         host_x2n_table[0] = p;
         for (int i = 1; i < 32; ++i) host_x2n_table[i] = p = mulmod(p, p);
-        host_x2n_ready = true;
-    }
+    });
     uint32_t p = 0x80000000u;
     while (n) {
         if (n & 1) p = mulmod(host_x2n_table[k & 31], p);
@@ -188,20 +227,20 @@ extern "C" {
 uint32_t zng_rocm_adler32(uint32_t adler, const uint8_t *buf, size_t len) {
     if (buf == nullptr) return 1u;                       // adler32_c.c:24-25
     uint32_t out[2];
-    run_host(true, false, adler, 0, buf, nullptr, len, out);
+    run_host_or_die(true, false, adler, 0, buf, nullptr, len, out, "zng_rocm_adler32");
     return out[0];
 }
 
 uint32_t zng_rocm_adler32_fold_copy(uint32_t adler, uint8_t *dst, const uint8_t *src, size_t len) {
     uint32_t out[2];
-    run_host(true, false, adler, 0, src, dst, len, out);
+    run_host_or_die(true, false, adler, 0, src, dst, len, out, "zng_rocm_adler32_fold_copy");
     return out[0];
 }
 
 uint32_t zng_rocm_crc32(uint32_t crc, const uint8_t *buf, size_t len) {
     if (buf == nullptr) return 0u;                       // export layer, crc32.c:22,28
     uint32_t out[2];
-    run_host(false, true, 0, crc, buf, nullptr, len, out);
+    run_host_or_die(false, true, 0, crc, buf, nullptr, len, out, "zng_rocm_crc32");
     return out[1];
 }
 
@@ -213,17 +252,63 @@ uint32_t zng_rocm_crc32_fold_reset(zng_rocm_crc32_fold_t *crc) {
 void zng_rocm_crc32_fold(zng_rocm_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc) {
     (void)init_crc;                                      // crc32_fold_c.c:20-27: ignored by the generic form
     uint32_t out[2];
-    run_host(false, true, 0, crc->value, src, nullptr, len, out);
+    run_host_or_die(false, true, 0, crc->value, src, nullptr, len, out, "zng_rocm_crc32_fold");
     crc->value = out[1];
 }
 
 void zng_rocm_crc32_fold_copy(zng_rocm_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len) {
     uint32_t out[2];
-    run_host(false, true, 0, crc->value, src, dst, len, out);
+    run_host_or_die(false, true, 0, crc->value, src, dst, len, out, "zng_rocm_crc32_fold_copy");
     crc->value = out[1];
 }
 
 uint32_t zng_rocm_crc32_fold_final(zng_rocm_crc32_fold_t *crc) { return crc->value; }
+
+// ---- the same slots with an error channel: 0 and the value through *out, or a ZNG_ROCM_E* code and nothing
+// written (SURVEY.md 8b "any HIP failure must degrade to the CPU implementation, never surface": the reference-side
+// adapter calls these and falls back to the CPU tier it remembered) --------------------
+int zng_rocm_adler32_try(uint32_t adler, const uint8_t *buf, size_t len, uint32_t *out) {
+    if (!out) return ZNG_ROCM_EINVAL;
+    if (buf == nullptr) { *out = 1u; return ZNG_ROCM_OK; }
+    uint32_t r[2];
+    if (int rc = run_host(true, false, adler, 0, buf, nullptr, len, r)) return rc;
+    *out = r[0];
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_adler32_fold_copy_try(uint32_t adler, uint8_t *dst, const uint8_t *src, size_t len, uint32_t *out) {
+    if (!out || (len && (!dst || !src))) return ZNG_ROCM_EINVAL;
+    uint32_t r[2];
+    if (int rc = run_host(true, false, adler, 0, src, dst, len, r)) return rc;
+    *out = r[0];
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_crc32_try(uint32_t crc, const uint8_t *buf, size_t len, uint32_t *out) {
+    if (!out) return ZNG_ROCM_EINVAL;
+    if (buf == nullptr) { *out = 0u; return ZNG_ROCM_OK; }
+    uint32_t r[2];
+    if (int rc = run_host(false, true, 0, crc, buf, nullptr, len, r)) return rc;
+    *out = r[1];
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_crc32_fold_try(zng_rocm_crc32_fold_t *crc, const uint8_t *src, size_t len, uint32_t init_crc) {
+    (void)init_crc;
+    if (!crc || (len && !src)) return ZNG_ROCM_EINVAL;
+    uint32_t r[2];
+    if (int rc = run_host(false, true, 0, crc->value, src, nullptr, len, r)) return rc;
+    crc->value = r[1];                                   // the state only moves on success
+    return ZNG_ROCM_OK;
+}
+
+int zng_rocm_crc32_fold_copy_try(zng_rocm_crc32_fold_t *crc, uint8_t *dst, const uint8_t *src, size_t len) {
+    if (!crc || (len && (!dst || !src))) return ZNG_ROCM_EINVAL;
+    uint32_t r[2];
+    if (int rc = run_host(false, true, 0, crc->value, src, dst, len, r)) return rc;
+    crc->value = r[1];
+    return ZNG_ROCM_OK;
+}
 
 int zng_rocm_adler32_combine_dev(const uint32_t *d_checks, const uint64_t *d_lens, size_t count, uint32_t *d_out,
                                  void *stream) {

@@ -37,6 +37,13 @@ _PROTOS = {
     "zng_rocm_last_error": (C.c_char_p, []),
     "zng_rocm_device_info": (C.c_int, [C.POINTER(C.c_int32)]),
     "zng_rocm_shutdown": (C.c_int, []),
+    "zng_rocm_stream_release": (C.c_int, [C.c_void_p]),
+    "zng_rocm_trace_stride": (C.c_int, [C.c_int]),
+    "zng_rocm_adler32_try": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "zng_rocm_adler32_fold_copy_try": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "zng_rocm_crc32_try": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "zng_rocm_crc32_fold_try": (C.c_int, [C.POINTER(Crc32FoldState), C.c_void_p, C.c_size_t, C.c_uint32]),
+    "zng_rocm_crc32_fold_copy_try": (C.c_int, [C.POINTER(Crc32FoldState), C.c_void_p, C.c_void_p, C.c_size_t]),
     "zng_rocm_adler32": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
     "zng_rocm_adler32_fold_copy": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zng_rocm_crc32": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_size_t]),
