@@ -304,18 +304,17 @@ int    zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *
                                 void *stream);
 
 /* ---- measurement hooks --------------------------------------------------
- * Between trace_begin and trace_end every launch of the DOMINANT kernel of a
- * *_dev entry point (the streaming kernel, not its finalize step) is bracketed
- * by a pair of HIP events recorded on the stream the kernel is launched on.
- * trace_end synchronises, writes the per-launch durations (ms) into `ms_out`
- * (up to `cap`) and returns how many launches were recorded (negative = error).
- * Used by bench.py for the roofline figure; no reference counterpart (the
- * reference measures with Google Benchmark, test/benchmarks/). */
+ * Between trace_begin and trace_end every (sampled) launch of the DOMINANT kernel of a *_dev entry point (the
+ * streaming kernel, not its finalize step) carries a pair of HIP events attached to its own dispatch
+ * (hipExtLaunchKernelGGL): the start / stop timestamps of the kernel itself, the quantity rocprofv3
+ * --kernel-trace reports, with no additional packets in the stream.  trace_end synchronises, writes the
+ * per-launch durations (ms) into `ms_out` (up to `cap`) and returns how many launches were recorded
+ * (negative = error).  Used by bench.py for the roofline figure; no reference counterpart (the reference
+ * measures with Google Benchmark, test/benchmarks/). */
 int zng_rocm_trace_begin(int max_launches);
 int zng_rocm_trace_end(float *ms_out, int cap);
-/* Bracket only every n-th marked launch (n >= 1; 1 = all, the default): an event pair in front of and behind a
- * launch costs launch gap, so a timed loop samples its kernel instead of perturbing every step.  Takes effect at
- * the next zng_rocm_trace_begin(). */
+/* Time only every n-th marked launch (n >= 1; 1 = all, the default): a timed loop can sample its kernel instead of
+ * attaching events to every step.  Takes effect at the next zng_rocm_trace_begin(). */
 int zng_rocm_trace_stride(int n);
 
 #ifdef __cplusplus

@@ -35,13 +35,15 @@ __global__ __launch_bounds__(1024) void null_kernel(Partial *p) {
 
 struct Run {
     const char *name;
-    void (*launch)(StreamArgs, const DeviceTables *, Partial *, int groups, hipStream_t);
+    void (*launch)(StreamArgs, const DeviceTables *, Partial *, int groups, hipStream_t, hipEvent_t, hipEvent_t);
     bool crc, adler, profile;
 };
 
-template <bool A, bool C, int V, bool P>
-static void launcher(StreamArgs sa, const DeviceTables *t, Partial *p, int groups, hipStream_t st) {
-    hipLaunchKernelGGL((stream_kernel<A, C, false, V, P>), dim3(groups), dim3(kWgThreads), 0, st, sa, t, p);
+// e0 / e1 non-null: events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's own timestamps
+template <bool A, bool C, int V, bool P, int U = 4>
+static void launcher(StreamArgs sa, const DeviceTables *t, Partial *p, int groups, hipStream_t st, hipEvent_t e0,
+                     hipEvent_t e1) {
+    hipExtLaunchKernelGGL((stream_kernel<A, C, false, V, P, U>), dim3(groups), dim3(kWgThreads), 0, st, e0, e1, 0, sa, t, p);
 }
 
 int main(int argc, char **argv) {
@@ -74,18 +76,21 @@ int main(int argc, char **argv) {
     const Run runs[] = {
         {"adler32", launcher<true, false, 0, false>, false, true, false},
         {"crc32 V=0 (round-1 form)", launcher<false, true, 0, false>, true, false, false},
-        {"crc32 V=1 both buffers first", launcher<false, true, 1, false>, true, false, false},
-        {"crc32 V=2 x32-table fold", launcher<false, true, 2, false>, true, false, false},
-        {"crc32 V=4 early partial products", launcher<false, true, 4, false>, true, false, false},
-        {"crc32 V=7 all three", launcher<false, true, 7, false>, true, false, false},
-        {"crc32 V=7+16 no replication (timing only)", launcher<false, true, 7 | 16, false>, true, false, false},
-        {"crc32 V=7+32 no multiply (timing only)", launcher<false, true, 7 | 32, false>, true, false, false},
-        {"crc32 V=7+48 neither (timing only)", launcher<false, true, 7 | 48, false>, true, false, false},
+        {"crc32 V=194 built, 4 rows early", launcher<false, true, 194, false>, true, false, false},
+        {"crc32 V=194+256 no rows early", launcher<false, true, 194 + 256, false>, true, false, false},
+        {"crc32 V=194+512 one row early", launcher<false, true, 194 + 512, false>, true, false, false},
+        {"crc32 V=194+768 two rows early", launcher<false, true, 194 + 768, false>, true, false, false},
+        {"crc32 V=195+256 none early, both bufs after", launcher<false, true, 195 + 256, false>, true, false, false},
+        {"crc32 V=195+512 one early, both bufs after", launcher<false, true, 195 + 512, false>, true, false, false},
+        {"crc32 V=195+768 two early, both bufs after", launcher<false, true, 195 + 768, false>, true, false, false},
         {"fused V=0", launcher<true, true, 0, false>, true, true, false},
-        {"fused V=7", launcher<true, true, 7, false>, true, true, false},
-        {"adler32 PROFILE", launcher<true, false, 0, true>, false, true, true},
-        {"crc32 V=0 PROFILE", launcher<false, true, 0, true>, true, false, true},
-        {"crc32 V=7 PROFILE", launcher<false, true, 7, true>, true, false, true},
+        {"fused V=194", launcher<true, true, 194, false>, true, true, false},
+        {"fused V=194+512", launcher<true, true, 194 + 512, false>, true, true, false},
+        {"fused V=195+512", launcher<true, true, 195 + 512, false>, true, true, false},
+        {"crc32 V=194 PROFILE", launcher<false, true, 194, true>, true, false, true},
+        {"crc32 V=194+256 PROFILE", launcher<false, true, 194 + 256, true>, true, false, true},
+        {"crc32 V=194+512 PROFILE", launcher<false, true, 194 + 512, true>, true, false, true},
+        {"crc32 V=195+512 PROFILE", launcher<false, true, 195 + 512, true>, true, false, true},
     };
 
     const int WARM = 300, REPS = 200;
@@ -105,6 +110,11 @@ int main(int argc, char **argv) {
         sa.head = 0;
         sa.tail = 0;
         sa.phase_stamps = stamps;
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 8; ++i) {
+                sa.bits.stride[k][i] = host_tabs.stride_tab[k][1u << i];
+                sa.bits.x32[k][i] = host_tabs.x32_tab[k][1u << i];
+            }
         int groups = cus;
         if (sa.nunits < groups) groups = (int)sa.nunits;
         FinalArgs fa;
@@ -139,14 +149,27 @@ int main(int argc, char **argv) {
             fa.do_adler = r.adler;
             fa.do_crc = r.crc;
             auto step = [&]() {
-                r.launch(sa, tabs, partials, groups, st);
+                r.launch(sa, tabs, partials, groups, st, nullptr, nullptr);
                 hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, fa, tabs, partials, out, out + 1);
             };
             for (int i = 0; i < WARM; ++i) step();
+            // (1) an event pair recorded in front of and behind the launch (round 1's trace_mark)
             for (int i = 0; i < REPS; ++i) {
                 CK(hipEventRecord(ea[i], st));
-                r.launch(sa, tabs, partials, groups, st);
+                r.launch(sa, tabs, partials, groups, st, nullptr, nullptr);
                 CK(hipEventRecord(eb[i], st));
+                hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, fa, tabs, partials, out, out + 1);
+            }
+            CK(hipStreamSynchronize(st));
+            double sum_pair = 0;
+            for (int i = 0; i < REPS; ++i) {
+                float v;
+                CK(hipEventElapsedTime(&v, ea[i], eb[i]));
+                sum_pair += v;
+            }
+            // (2) the events attached to the dispatch: the kernel's own start / stop
+            for (int i = 0; i < REPS; ++i) {
+                r.launch(sa, tabs, partials, groups, st, ea[i], eb[i]);
                 hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, fa, tabs, partials, out, out + 1);
             }
             CK(hipStreamSynchronize(st));
@@ -156,6 +179,13 @@ int main(int argc, char **argv) {
                 CK(hipEventElapsedTime(&ms[i], ea[i], eb[i]));
                 sum += ms[i];
             }
+            // (3) throughput: REPS steps back to back between two events
+            CK(hipEventRecord(ea[0], st));
+            for (int i = 0; i < REPS; ++i) step();
+            CK(hipEventRecord(eb[0], st));
+            CK(hipStreamSynchronize(st));
+            float loop_ms;
+            CK(hipEventElapsedTime(&loop_ms, ea[0], eb[0]));
             std::sort(ms.begin(), ms.end());
             uint32_t h[2];
             CK(hipMemcpy(h, out, 8, hipMemcpyDeviceToHost));
@@ -169,8 +199,9 @@ int main(int argc, char **argv) {
                 if (!ref_adler) ref_adler = h[0];
                 if (h[0] != ref_adler) verdict = " ADLER DIFFERS";
             }
-            printf("%-46s %8.2f us (median %7.2f)  %6.3f of 8 TB/s%s\n", r.name, us, ms[REPS / 2] * 1e3,
-                   (double)n / 1e9 / (us * 1e-6) / 8000.0, verdict);
+            printf("%-46s dispatch %7.2f us (median %7.2f) %5.3f of 8 TB/s | event pair %7.2f | step in a loop %7.2f%s\n",
+                   r.name, us, ms[REPS / 2] * 1e3, (double)n / 1e9 / (us * 1e-6) / 8000.0, sum_pair / REPS * 1e3,
+                   loop_ms / REPS * 1e3, verdict);
             if (r.profile) {
                 std::vector<unsigned long long> hs(8 * (size_t)groups);
                 CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));

@@ -63,6 +63,11 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     sa.head = (int)(p - a0);
     sa.tail = (int)((p + len) - tail_base);
     sa.phase_stamps = nullptr;
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) {
+            sa.bits.stride[k][i] = c->host_tables.stride_tab[k][1u << i];
+            sa.bits.x32[k][i] = c->host_tables.x32_tab[k][1u << i];
+        }
 
     FinalArgs fa;
     fa.tail_base = (const uint8_t *)tail_base;
@@ -84,9 +89,8 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     fa.groups = groups;
     if (sa.nunits > 0) {
         dim3 grid(groups), block(kWgThreads);
-        trace_mark(stream, true);
 #define ZR_LAUNCH(A, C, K) \
-        hipLaunchKernelGGL((stream_kernel<A, C, K>), grid, block, 0, stream, sa, c->tables, ws->partials)
+        ZR_LAUNCH_TRACED((stream_kernel<A, C, K>), grid, block, stream, sa, c->tables, ws->partials)
         if (copy) {
             if (do_adler && do_crc) ZR_LAUNCH(true, true, true);
             else if (do_adler) ZR_LAUNCH(true, false, true);
@@ -97,7 +101,6 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
             else ZR_LAUNCH(false, true, false);
         }
 #undef ZR_LAUNCH
-        trace_mark(stream, false);
         ZR_HIP(hipGetLastError());
     } else {
         ZR_HIP(hipMemsetAsync(ws->partials, 0, sizeof(Partial) * groups, stream));

@@ -44,6 +44,15 @@ __device__ __forceinline__ uint4 ld_stream(const uint8_t *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() drains vmcnt as well, i.e. it waits for every global
+// load the wave has in flight -- here the first 128 KiB of the pass, requested on purpose before the tables are built:
+// measured, each __syncthreads() of the prologue then sat ~3 us on the HBM latency it was meant to overlap.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // first `k` bytes (k in 0..15) of a piece -> 0
 __device__ __forceinline__ uint4 mask_low_bytes(uint4 v, int k) {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -66,6 +75,15 @@ __device__ __forceinline__ uint32_t braid_step(const uint32_t *lut, uint32_t rep
     return r0 ^ r1 ^ r2 ^ r3 ^ w;
 }
 
+// What the CRC prologue needs to BUILD its tables in registers instead of fetching them: entry e of a table that is
+// linear over GF(2) is the XOR of the entries of e's set bits, so eight words per table suffice.  They travel as
+// kernel arguments (scalar loads from the kernarg segment): the prologue touches no table in HBM at all -- measured,
+// the fetch of the 9 KiB of tables cost 2.1-2.6 us per launch (L2 is flushed by the pass between two launches).
+struct CrcBits {
+    uint32_t stride[4][8];    // stride_tab[k][1 << i]
+    uint32_t x32[4][8];       // x32_tab[k][1 << i]
+};
+
 struct StreamArgs {
     const uint8_t *a0;        // 16-byte aligned
     uint8_t       *dst0;      // COPY: destination of byte a0[0] (same 16-byte phase as a0), else unused
@@ -75,6 +93,7 @@ struct StreamArgs {
     int            head;      // buf - a0, 0..15
     int            tail;      // bytes of the message living in the granule at tail_base
     unsigned long long *phase_stamps;   // tools/micro only (PROFILE instantiations): 8 stamps per workgroup
+    CrcBits        bits;
 };
 
 // Tuning switches of the CRC prologue / epilogue (bit mask V).  The product instantiates kCrcVariant only; the others
@@ -84,10 +103,17 @@ constexpr int kVarFoldX32     = 2;    // braid fold through x^32 tables: 3 LDS l
 constexpr int kVarEarlyPow    = 4;    // fetch the lane's 32 partial products before the main loop, not after it
 constexpr int kVarNoReplicate = 16;   // TIMING ONLY (wrong CRC): skip the 128 KiB replication
 constexpr int kVarNoMultiply  = 32;   // TIMING ONLY (wrong CRC): skip the per-lane weight multiply
-constexpr int kCrcVariant = kVarBothBuffers | kVarFoldX32 | kVarEarlyPow;
+constexpr int kVarBuildTables = 64;   // build the table entries in registers from CrcBits: no table fetch in the prologue
+constexpr int kVarLdsBarrier  = 128;  // prologue barriers wait for LDS only, not for the data loads already in flight
+constexpr int kVarEarlyRows   = 768;  // two bits: how many rows of group 0 are requested BEFORE the table build when
+                                      //   kVarBuildTables is on: 0 -> all (4), 256 -> none, 512 -> one, 768 -> two
+// Measured on MI355X (tools/micro/crc_phases.hip, profiles/r02_crc_phases.md), crc32 over 64 MiB, dispatch time:
+// round-1 form 17.9 us; this combination 17.05 us.  Requesting the second buffer, more rows, or the lane products
+// before the table work made it SLOWER: a CU accepts only so many loads in flight, the wave stalls at issue.
+constexpr int kCrcVariant = kVarFoldX32 | kVarBuildTables | kVarLdsBarrier;
 
 // DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
-template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false>
+template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false, int UNROLL = 4>
 __global__ __launch_bounds__(kWgThreads)
 void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
     __shared__ uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
@@ -115,7 +141,6 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
 
     // Main-loop geometry first, so that the first group(s) of HBM loads can be issued BEFORE the tables are built:
     // their latency then runs under the table build instead of after it.
-    constexpr int UNROLL = 4;
     const bool head_unit = u_lo < u_hi && u_lo == 0;     // the message's first unit is handled apart (head mask)
     const long long groups = (u_hi - u_lo - (head_unit ? 1 : 0)) / UNROLL;
     const long long gstride = (long long)UNROLL * kUnitBytes;
@@ -129,35 +154,77 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     uint32_t group_w0 = 0, group_w1 = 0;
     uint32_t part[32];                   // the lane's 32 partial products (epilogue multiply)
     if constexpr (DO_CRC) {
-        // tables: HBM/L2 -> LDS once (9 KiB, one dwordx4 per lane of the first 9 waves), then replicated LDS -> LDS:
-        // 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent dwords
-        uint4 tab = make_uint4(0, 0, 0, 0);
-        if (t < 256) {
-            tab = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
-        } else if (t < 320) {
-            tab = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
-        } else if (t < 576) {
-            tab = reinterpret_cast<const uint4 *>(&tabs->x32_tab[0][0])[t - 320];
-        }
         // the two digits of this group's end-of-body weight (epilogue, thread 0): fetched now, not on the tail
         const unsigned long long k_after = (unsigned long long)(args.nunits - u_hi);
-        group_w0 = tabs->unit_pow[0][k_after & 1023u];
-        group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
-        if (groups > 0) request(bufA, first_at);
-        if constexpr ((V & kVarBothBuffers) != 0) {
-            if (groups > 1) {
-                request(bufB, first_at + gstride);
-                b_requested = true;
-            }
-        }
-        if constexpr ((V & kVarEarlyPow) != 0) {
+        if constexpr ((V & kVarBuildTables) != 0) {
+            // A CU takes only so many loads in flight; a wave that asks for more stalls at ISSUE and with it everything
+            // behind the load in its instruction stream.  So only the first rows are requested before the table work.
+            constexpr int early = (V & kVarEarlyRows) == 0 ? UNROLL : ((V & kVarEarlyRows) >> 8) - 1;
+            if (groups > 0) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
+                for (int j = 0; j < early; ++j) bufA[j] = ld_stream(args.a0 + first_at + (long long)j * kUnitBytes);
+            }
+            if constexpr ((V & kVarBothBuffers) != 0 && early == UNROLL) {
+                if (groups > 1) {
+                    request(bufB, first_at + gstride);
+                    b_requested = true;
+                }
+            }
+            group_w0 = tabs->unit_pow[0][k_after & 1023u];
+            group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
+            if constexpr ((V & kVarEarlyPow) != 0) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
+            }
+            // lane t builds entry e = t % 256 of stride table and of x^32 table k = t / 256 (k is wave-uniform), and the
+            // first 256 lanes one byte-table entry each (the shift register of tools/makecrct.c:66-73)
+            const int k = __builtin_amdgcn_readfirstlane(t >> 8);
+            const uint32_t e = (uint32_t)t & 255u;
+            uint32_t sv = 0, xv = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t m = 0u - ((e >> i) & 1u);
+                sv ^= args.bits.stride[k][i] & m;
+                xv ^= args.bits.x32[k][i] & m;
+            }
+            stage[t] = sv;
+            stage[1280 + t] = xv;
+            if (t < 256) {
+                uint32_t r = e;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r = (r >> 1) ^ (kCrcPoly & (0u - (r & 1u)));
+                stage[1024 + t] = r;
+            }
+        } else {
+            // tables: HBM/L2 -> LDS once (9 KiB, one dwordx4 per lane of the first 9 waves)
+            uint4 tab = make_uint4(0, 0, 0, 0);
+            if (t < 256) {
+                tab = reinterpret_cast<const uint4 *>(&tabs->stride_tab[0][0])[t];
+            } else if (t < 320) {
+                tab = reinterpret_cast<const uint4 *>(tabs->byte_tab)[t - 256];
+            } else if (t < 576) {
+                tab = reinterpret_cast<const uint4 *>(&tabs->x32_tab[0][0])[t - 320];
+            }
+            group_w0 = tabs->unit_pow[0][k_after & 1023u];
+            group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
+            if (groups > 0) request(bufA, first_at);
+            if constexpr ((V & kVarBothBuffers) != 0) {
+                if (groups > 1) {
+                    request(bufB, first_at + gstride);
+                    b_requested = true;
+                }
+            }
+            if constexpr ((V & kVarEarlyPow) != 0) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
+            }
+            if (t < 576) reinterpret_cast<uint4 *>(stage)[t] = tab;
         }
-        if (t < 576) reinterpret_cast<uint4 *>(stage)[t] = tab;
-        __syncthreads();
+        if constexpr ((V & kVarLdsBarrier) != 0) lds_barrier();
+        else __syncthreads();
         stamp(1);
-        // entry e sits in lut[32 e .. 32 e + 31]: eight lanes write one entry, four replicas (one b128) each
+        // replicated LDS -> LDS: 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent
+        // dwords: eight lanes write one entry, four replicas (one b128) each
         if constexpr ((V & kVarNoReplicate) == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -165,7 +232,21 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
                 reinterpret_cast<uint4 *>(lut)[i * kWgThreads + t] = make_uint4(v, v, v, v);
             }
         }
-        __syncthreads();
+        if constexpr ((V & kVarLdsBarrier) != 0) lds_barrier();
+        else __syncthreads();
+        if constexpr ((V & kVarBuildTables) != 0 && (V & kVarEarlyRows) != 0) {
+            constexpr int early = ((V & kVarEarlyRows) >> 8) - 1;
+            if (groups > 0) {
+#pragma unroll
+                for (int j = early; j < UNROLL; ++j) bufA[j] = ld_stream(args.a0 + first_at + (long long)j * kUnitBytes);
+            }
+            if constexpr ((V & kVarBothBuffers) != 0) {
+                if (groups > 1) {
+                    request(bufB, first_at + gstride);
+                    b_requested = true;
+                }
+            }
+        }
     } else {
         if (groups > 0) request(bufA, first_at);
     }

@@ -2,6 +2,7 @@
 // constant tables in HBM, per-stream workspaces and scratch, bounded staging, error state.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -99,8 +100,16 @@ void set_error(const char *fmt, ...);
         }                                                                       \
     } while (0)
 
-// measurement hooks (zng_rocm_trace_begin/_end): event pair around the dominant kernel
-void trace_mark(hipStream_t s, bool begin);
+// measurement hooks (zng_rocm_trace_begin/_end): when this launch of a dominant kernel is to be timed, hands out the
+// event pair to ATTACH to its dispatch (hipExtLaunchKernelGGL: the kernel's own start / stop timestamps, what
+// rocprofv3 --kernel-trace reports, with no extra packets in the stream); otherwise leaves both null
+void trace_pick(hipEvent_t *start, hipEvent_t *stop);
+#define ZR_LAUNCH_TRACED(kernel, grid, block, stream, ...)                                          \
+    do {                                                                                            \
+        hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                  \
+        zr::trace_pick(&ev0_, &ev1_);                                                               \
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev0_, ev1_, 0, __VA_ARGS__);          \
+    } while (0)
 
 Context   *ctx();                          // nullptr until zng_rocm_init succeeded
 Workspace *workspace_for(hipStream_t s);   // lazily created on the context's device, nullptr on failure

@@ -57,22 +57,16 @@ DeviceGuard::~DeviceGuard() {
 static std::mutex g_tr_mu;
 static std::vector<hipEvent_t> g_tr_start, g_tr_stop;
 static int g_tr_cap = 0, g_tr_n = 0, g_tr_stride = 1, g_tr_seen = 0;
-static bool g_tr_open = false;                 // a begin mark was recorded and waits for its end mark
 static std::atomic<bool> g_tr_on{false};
 
-void trace_mark(hipStream_t s, bool begin) {
+void trace_pick(hipEvent_t *start, hipEvent_t *stop) {
     if (!g_tr_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_tr_mu);
     if (!g_tr_on.load(std::memory_order_relaxed) || g_tr_n >= g_tr_cap) return;
-    if (begin) {
-        if (g_tr_seen++ % g_tr_stride) return;
-        (void)hipEventRecord(g_tr_start[g_tr_n], s);
-        g_tr_open = true;
-    } else if (g_tr_open) {
-        (void)hipEventRecord(g_tr_stop[g_tr_n], s);
-        g_tr_open = false;
-        ++g_tr_n;
-    }
+    if (g_tr_seen++ % g_tr_stride) return;
+    *start = g_tr_start[g_tr_n];
+    *stop = g_tr_stop[g_tr_n];
+    ++g_tr_n;
 }
 
 static void free_workspace(Workspace *ws) {
@@ -253,7 +247,6 @@ int zng_rocm_trace_begin(int max_launches) {
     }
     g_tr_cap = max_launches;
     g_tr_n = g_tr_seen = 0;
-    g_tr_open = false;
     g_tr_on.store(true);
     return ZNG_ROCM_OK;
 }

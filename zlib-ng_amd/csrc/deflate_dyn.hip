@@ -673,9 +673,7 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         unsigned grid = (unsigned)((pieces + 255) / 256);
         if (grid > 65536u) grid = 65536u;
         if (grid == 0) grid = 1;
-        trace_mark(st, true);
-        hipLaunchKernelGGL(stored_kernel, dim3(grid), dim3(256), 0, st, d_in, in_len, d_out);
-        trace_mark(st, false);
+        ZR_LAUNCH_TRACED(stored_kernel, dim3(grid), dim3(256), st, d_in, in_len, d_out);
         ZR_HIP(hipGetLastError());
         ZR_HIP(hipStreamSynchronize(st));
         *out_len = total0;
@@ -720,10 +718,7 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
     ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
 
-    trace_mark(st, true);
-    hipLaunchKernelGGL(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), 0, st, d_jobs, d_sel, max_chain,
-                       good_match);
-    trace_mark(st, false);
+    ZR_LAUNCH_TRACED(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), st, d_jobs, d_sel, max_chain, good_match);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_sel, d_seg_len);
     ZR_HIP(hipGetLastError());

@@ -301,9 +301,7 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     if (int rc = scratch_reserve(ws, kScrQuickSel, (total + 1024) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
     ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     if (int rc = host_tables_release(ws, st)) return rc;
-    trace_mark(st, true);
-    hipLaunchKernelGGL(lz_parse_kernel, dim3((unsigned)njobs), dim3(256), 0, st, d_jobs, d_sel);
-    trace_mark(st, false);
+    ZR_LAUNCH_TRACED(lz_parse_kernel, dim3((unsigned)njobs), dim3(256), st, d_jobs, d_sel);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_static_kernel, dim3((unsigned)njobs), dim3(256), 0, st, d_jobs, d_sel, d_results);
     ZR_HIP(hipGetLastError());
