@@ -46,7 +46,6 @@ struct Partial {            // one per workgroup, written by the streaming kerne
 enum ScratchSlot {
     kScrQuickJobs = 0,      // device: StreamJobDev[] of zng_rocm_deflate_quick_dev
     kScrQuickJobsHost,      // pinned host mirror of the same (async H2D source)
-    kScrQuickSel,           // device: selectors of the level-1 class
     kScrDynJobs,            // device: SegJob[] of zng_rocm_deflate_dev
     kScrDynJobsHost,        // pinned
     kScrDynSel,             // device: one 32-bit selector per input byte (level-6 class)

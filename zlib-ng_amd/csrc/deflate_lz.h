@@ -8,7 +8,9 @@
 //      had the 64 positions been inserted one after the other; the four waves of a batch take turns.
 //      (Correctness never depends on that order: every candidate is verified byte by byte.)
 //   2. per-lane probe: first kLzProbe bytes against the candidate (the zng_memcmp_2 + compare256 of
-//      deflate_quick.c:96-97, bounded).
+//      deflate_quick.c:96-97, bounded).  The lane's own 16 bytes arrive with the batch (one contiguous prefetch a
+//      batch ahead); the candidate's 16 bytes are ONE unaligned dwordx4 gather, so a batch has one dependent memory
+//      round trip on its critical path -- a second one only for the lanes whose first 16 bytes all agree.
 //   3. parse.  A greedy parse is a serial chain through the whole stream; here every 64-position REGION
 //      (one wave) parses speculatively from its own first byte, all regions at once: ballot(len >= 4),
 //      hop from match to match with ctz, extend long matches with the wavefront-wide compare256.
@@ -26,7 +28,7 @@
 namespace zr {
 
 constexpr uint32_t kLzMaxDist = 32768u - kMinLookahead;       // MAX_DIST(s)
-constexpr uint32_t kLzProbe = 36;                             // bytes compared per lane before the parse
+constexpr uint32_t kLzProbe = 32;                             // bytes compared per lane before the parse
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
 constexpr uint32_t kLzNone = 0xffffffffu;
 
@@ -72,19 +74,37 @@ struct LzPick {
     uint32_t len, dist;
 };
 
+// bytes [p, p + 16) of the stream; bytes at or beyond n read as 0 (only the last batches of a stream get here)
+__device__ __forceinline__ u32x4_unaligned load_16_guarded(const uint8_t *in, uint32_t p, uint32_t n) {
+    if (p + 16u <= n && p + 16u >= p) return load_u128(in + p);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t j = 0; j < 16u && p + j < n && p + j >= p; ++j) w[j >> 2] |= (uint32_t)load_u8(in + p + j) << (8u * (j & 3u));
+    u32x4_unaligned r = {w[0], w[1], w[2], w[3]};
+    return r;
+}
+
+// number of equal leading bytes of two 16-byte pieces (16 = all equal)
+__device__ __forceinline__ uint32_t lz_prefix16(const u32x4_unaligned &a, const u32x4_unaligned &b) {
+    const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+    uint32_t l = 16;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) l = x[j] ? 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x[j]) - 1) >> 3) : l;
+    return l;
+}
+
 // One batch of the level-1 class: a single chain-head probe per position (deflate_quick.c:89-97).
-// `val` = the 4 bytes at this lane's position (0 if fewer remain).
+// `own` = the 16 bytes at this lane's position (zero beyond the end of the stream).
 // FULL: the caller guarantees that every position of the batch has its whole 258-byte lookahead inside the stream
 // (all batches but the last two of a stream) -- lim, maxlen and the end-of-input guards fold to constants, which
 // matters because the scalar instructions they cost are the kernel's bound.
 template <int HBITS, int NW = 4, bool FULL = false>   // NW = wavefronts per workgroup (batch = 64 * NW positions)
-__device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P, uint32_t val,
-                                           LzShared<HBITS> *sh, int t) {
+__device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint32_t n, uint32_t P,
+                                           const u32x4_unaligned &own, LzShared<HBITS> *sh, int t) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);        // wave-uniform: keeps the parse scalar
     const uint32_t p = P + (uint32_t)t;
     const bool can = FULL || p + kLzMinMatch <= n;      // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
-    const uint32_t h = lz_hash<HBITS>(val);
+    const uint32_t h = lz_hash<HBITS>(own.x);
 
     // 1. insert, waves in position order
     uint32_t old = 0;
@@ -93,34 +113,19 @@ __device__ __forceinline__ LzPick lz_batch(const uint8_t *__restrict__ in, uint3
         __syncthreads();
     }
 
-    // 2. probe
+    // 2. probe: one gather of the candidate's first 16 bytes; a second round only behind 16 equal bytes
     uint32_t len = 0, dist = 0;
     const uint32_t maxlen = FULL ? kStdMaxMatch : (p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u);
     {
-        if (old) {
-            const uint32_t c = old - 1u;
-            // Staged probe: the candidate side is a per-lane gather (every lane its own cache line), which is what
-            // this kernel is bound by -- so 4 bytes first (most candidates die there), then 16, then 16 more.
-            if (c < p && p - c <= kLzMaxDist && load_u32(in + c) == val) {
-                uint32_t l = 4;
-#pragma unroll
-                for (int stage = 0; stage < 2 && l == 4u + 16u * (uint32_t)stage; ++stage) {
-                    if (l + 16 <= maxlen) {
-                        const u32x4_unaligned a = load_u128(in + p + l), b = load_u128(in + c + l);
-                        const uint32_t x[4] = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
-                        uint32_t add = 16;
-#pragma unroll
-                        for (int j = 3; j >= 0; --j)
-                            if (x[j]) add = 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x[j]) - 1) >> 3);
-                        l += add;
-                    } else {
-                        while (l < maxlen && load_u8(in + p + l) == load_u8(in + c + l)) ++l;
-                        break;
-                    }
-                }
-                len = l;                                  // 36 = both stages matched: the parse extends it
-                dist = p - c;
-            }
+        const uint32_t c = old - 1u;                     // old == 0 -> 0xffffffff: fails c < p
+        if (c < p && p - c <= kLzMaxDist) {
+            uint32_t l = lz_prefix16(FULL ? load_u128(in + c) : load_16_guarded(in, c, n), own);
+            if (l == 16u && maxlen > 16u)
+                l += lz_prefix16(FULL ? load_u128(in + c + 16u) : load_16_guarded(in, c + 16u, n),
+                                 FULL ? load_u128(in + p + 16u) : load_16_guarded(in, p + 16u, n));
+            l = l < maxlen ? l : maxlen;
+            len = l >= kLzMinMatch ? l : 0u;             // kLzProbe = both rounds matched: the parse extends it
+            dist = p - c;
         }
     }
 
