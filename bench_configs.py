@@ -152,14 +152,23 @@ def main():
         rng = np.random.default_rng(0xC0B1)
         src_bytes = (64 if args.quick else 256) << 20
         base = torch.randint(0, 256, (2 * src_bytes + 4096,), dtype=torch.uint8, device="cuda")
-        for name, lens in (
-                ("len 258 (the inflate caller's maximum)", np.full(src_bytes // 258, 258, dtype=np.uint32)),
-                ("len 256", np.full(src_bytes // 256, 256, dtype=np.uint32)),
-                ("len uniform 3..258", rng.integers(3, 259, size=src_bytes // 131, dtype=np.uint32)),
-                ("len 4096", np.full(src_bytes // 4096, 4096, dtype=np.uint32))):
+        for name, lens, window in (
+                ("len 258 (the inflate caller's maximum)", np.full(src_bytes // 258, 258, dtype=np.uint32), False),
+                ("len 256", np.full(src_bytes // 256, 256, dtype=np.uint32), False),
+                ("len uniform 3..258, sources anywhere in 256 MiB", rng.integers(3, 259, size=src_bytes // 131, dtype=np.uint32), False),
+                ("len uniform 3..258, sources <= 32 KiB behind (the inflate caller's window)",
+                 rng.integers(3, 259, size=src_bytes // 131, dtype=np.uint32), True),
+                ("len 4096", np.full(src_bytes // 4096, 4096, dtype=np.uint32), False)):
             ncopy = lens.size
-            out_off = src_bytes + np.concatenate(([0], np.cumsum(lens[:-1], dtype=np.uint64))).astype(np.uint64)
-            from_off = rng.integers(0, src_bytes - 4096, size=ncopy, dtype=np.uint64)
+            rel = np.concatenate(([0], np.cumsum(lens[:-1], dtype=np.uint64))).astype(np.uint64)
+            out_off = src_bytes + rel
+            if window:
+                # the source of copy i sits dist in [len, 32768] bytes behind the copy's own position, in the first
+                # region (the batch's copies must not depend on each other, so the "history" is a second buffer)
+                dist = rng.integers(0, 32768 - 258, size=ncopy, dtype=np.uint64) + lens
+                from_off = np.where(rel + 32768 > dist, rel + 32768 - dist, 0).astype(np.uint64)
+            else:
+                from_off = rng.integers(0, src_bytes - 4096, size=ncopy, dtype=np.uint64)
             d_out = torch.from_numpy(out_off.view(np.int64)).cuda()
             d_from = torch.from_numpy(from_off.view(np.int64)).cuda()
             d_len = torch.from_numpy(lens.view(np.int32)).cuda()

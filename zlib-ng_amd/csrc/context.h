@@ -54,6 +54,7 @@ enum ScratchSlot {
     kScrDynSegLenHost,      // pinned
     kScrDynDstOff,          // device: u64 per segment
     kScrDynDstOffHost,      // pinned
+    kScrChunkList,          // device: work list of zng_rocm_chunkmemset_safe_dev (long / memmove-order copies)
     kScrInflate,            // device: tokens | segs | literals | symbols of the one-shot inflate
     kScrInflateHost,        // pinned token staging of the batched inflate
     kScrCount
