@@ -207,19 +207,31 @@ uint32_t zng_rocm_chunksize(void);
 
 /* ---- whole-stream deflate on device, many independent streams (level-1 class) -------------
  * The caller this replaces is deflate_quick (deflate_quick.c:47-130) behind DEFLATE_HOOK
- * (deflate.c:1039): one raw RFC 1951 stream per job, a single final static-Huffman block, built
- * from the same primitives (insert_string hash, single chain-head probe, compare256, static trees)
- * run wavefront-wide with the head table in LDS.  Output is valid deflate that any inflater
- * restores to the input; it is not bit-identical to the reference's stream.
- *   in:  device, 16-byte aligned, readable up to the next 16-byte boundary past in_len
+ * (deflate.c:1039): per job ONE static-Huffman block of raw RFC 1951, built from the same primitives
+ * (insert_string hash, single chain-head probe, compare256, static trees) run wavefront-wide with the
+ * head table in LDS and the bit assembly in LDS (one kernel; nothing but input and output touches HBM).
+ * Output is valid deflate that any inflater restores to the input; it is not bit-identical to the
+ * reference's stream.
+ *   in:  device; any alignment; `dict_len` (<= 32768) bytes of history sit directly in front of it
+ *        (in - dict_len .. in): they prime the hash as deflateSetDictionary does (deflate.c:456-531) and
+ *        matches may reach back into them, but they are neither emitted nor part of the checksum
  *   out: device, 4-byte aligned, out_cap >= zng_rocm_deflate_quick_bound(in_len)
+ *   flags: 0 = the block is the stream's last (BFINAL = 1: what one deflate(Z_FINISH) call emits);
+ *        ZNG_ROCM_BLOCK_NOT_FINAL = BFINAL 0; with ZNG_ROCM_BLOCK_SYNC_FLUSH an empty stored block follows
+ *        (00 00 ff ff after the padding bits: the Z_SYNC_FLUSH marker, deflate.c:1064-1076), so the job's
+ *        output is a whole number of bytes and jobs CONCATENATE into one valid stream -- the pigz scheme:
+ *        blocks of one input compressed independently, each primed with the 32 KiB before it.
  * `jobs` is a HOST array (copied internally).  d_results (device) receives per job
  * {compressed length, adler32(1, in, in_len)} -- the {clen, check} row of the multi-stream table. */
+#define ZNG_ROCM_BLOCK_NOT_FINAL  1u
+#define ZNG_ROCM_BLOCK_SYNC_FLUSH 2u
 typedef struct zng_rocm_stream_job {
     const uint8_t *in;
     uint8_t       *out;
     uint32_t       in_len;
     uint32_t       out_cap;
+    uint32_t       dict_len;
+    uint32_t       flags;
 } zng_rocm_stream_job;
 size_t zng_rocm_deflate_quick_bound(size_t source_len);
 int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, uint32_t *d_results, void *stream);
@@ -237,10 +249,15 @@ int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs,
  * split that function makes when input and output are both complete (:46-95).  d_out needs
  * zng_rocm_deflate_bound(in_len) bytes.
  * Synchronises `stream` (the segment lengths are prefix-summed on the host).  Returns 0, a ZNG_ROCM_E* code, or
- * -5 (Z_BUF_ERROR). */
+ * -5 (Z_BUF_ERROR).
+ * zng_rocm_deflate_block_dev is the same for one BLOCK of a longer stream: `dict_len` (<= 32768) bytes of history
+ * in front of d_in prime the first segment, and `flags` (ZNG_ROCM_BLOCK_*, above) say whether the stream ends
+ * here; a non-final block always ends byte aligned behind an empty stored block. */
 size_t zng_rocm_deflate_bound(size_t source_len);
 int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
                             size_t *out_len, void *stream);
+int    zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags,
+                                  uint8_t *d_out, size_t out_cap, size_t *out_len, void *stream);
 
 /* ---- inflate: host bitstream decode -> token stream -> device copy resolution -------------
  * The split of slot `inflate_fast` (inffast_tpl.h:53-318): the sequential Huffman decode loop
@@ -266,6 +283,12 @@ typedef struct zng_rocm_inflate_tokens {
 } zng_rocm_inflate_tokens;
 
 int  zng_rocm_inflate_tokens_decode(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *out);
+/* the same for a stream that continues history: `window_len` (<= 32768) bytes precede its first byte -- a preset
+ * dictionary (inflateSetDictionary on a raw stream, inflate.c:1214-1261) or the last bytes an earlier call produced
+ * (inflate's sliding window, inflate.c:325-378) -- so a distance may reach that far beyond the start of the output
+ * before it is "invalid distance too far back" (inffast_tpl.h:198-226 with whave = window_len) */
+int  zng_rocm_inflate_tokens_decode_window(const uint8_t *src, size_t src_len, uint32_t window_len,
+                                           zng_rocm_inflate_tokens *out);
 void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
 /* Device stage on device-resident token arrays.  d_symbols: workspace of out_len uint16_t;
  * d_out: out_len bytes.  Up to four launches: per-segment resolution into 16-bit symbols (a symbol
@@ -275,6 +298,12 @@ void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
 int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
                                   size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
                                   uint8_t *d_out, uint64_t out_len, void *stream);
+/* resolve with a prior window: `d_window` holds the window_len bytes that precede the stream (device);
+ * d_symbols must then have room for 32768 + out_len uint16_t (the window's symbols are laid in front) */
+int  zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
+                                         size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
+                                         uint8_t *d_out, uint64_t out_len, const uint8_t *d_window,
+                                         uint32_t window_len, void *stream);
 /* One-shot raw inflate (windowBits < 0): host stream in, plaintext left in device memory at d_dst.
  * Returns the zlib status of the decode (1 = Z_STREAM_END) or a negative ZNG_ROCM_E* / Z_* code;
  * *out_len = bytes produced.  -5 also when dst_cap is too small. */
@@ -284,6 +313,10 @@ int  zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, si
 /* as zng_rocm_inflate_raw, also reporting how many input bytes the deflate stream occupied */
 int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                              size_t *in_used, void *stream);
+
+/* ... and of a stream that continues `window_len` bytes of device-resident history (dictionary / sliding window) */
+int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                 uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
 /* ---- compress2 / uncompress2 class front ends (compress.c:31-98, uncompr.c:25-76) ---------------------
  * `format`: 0 = raw deflate, 1 = zlib (RFC 1950), 2 = gzip (RFC 1952).  The trailer checksum (Adler-32 /

@@ -20,6 +20,7 @@
  * One-shot semantics: all input present, one output buffer, so "too far back" means a distance
  * larger than the number of bytes produced so far (inffast_tpl.h:198-226 with whave == 0).
  */
+#include <stdlib.h>
 #include <string.h>
 #include "zng_oracle.h"
 
@@ -117,10 +118,12 @@ static const uint16_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5
 #define FAIL(m) do { res->status = ORACLE_Z_DATA_ERROR; res->msg = (m); goto done; } while (0)
 #define STARVED() do { res->status = ORACLE_Z_BUF_ERROR; res->msg = "input ended before the final block"; goto done; } while (0)
 
-int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
-                       oracle_inflate_result *res) {
+/* `dst` holds `start` bytes of history (a preset dictionary: inflateSetDictionary, inflate.c:1214-1261, makes them
+ * the window, whave = start) in front of where the output goes; dst_cap counts from dst[0]. */
+static int inflate_core(const uint8_t *src, size_t src_len, uint8_t *dst, size_t start, size_t dst_cap,
+                        oracle_inflate_result *res) {
     bitreader br = { src, src_len, 0, 0, 0, 0 };
-    size_t out = 0;
+    size_t out = start;
     huff lencode, distcode, clcode;
     uint16_t lens[MAXL + MAXD];
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -237,7 +240,34 @@ int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t 
     } while (!last);
     res->status = ORACLE_Z_STREAM_END;
 done:
-    res->out_len = out;
+    res->out_len = out - start;
     res->in_used = br.in_pos - (size_t)(br.bitcnt >> 3);   /* whole unread bytes are handed back */
     return res->status;
+}
+
+int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
+                       oracle_inflate_result *res) {
+    return inflate_core(src, src_len, dst, 0, dst_cap, res);
+}
+
+/* raw inflate after inflateSetDictionary(dict, dict_len) (inflate.c:1214-1261; only the last 32 KiB count,
+ * inflate.c:325-378 updatewindow): distances may reach dict_len bytes in front of the output */
+int oracle_inflate_raw_dict(const uint8_t *src, size_t src_len, const uint8_t *dict, size_t dict_len,
+                            uint8_t *dst, size_t dst_cap, oracle_inflate_result *res) {
+    if (dict_len > 32768) {
+        dict += dict_len - 32768;
+        dict_len = 32768;
+    }
+    uint8_t *work = (uint8_t *)malloc(dict_len + dst_cap + 1);
+    if (!work) {
+        res->status = -4;
+        res->msg = "out of memory";
+        res->out_len = res->in_used = 0;
+        return res->status;
+    }
+    memcpy(work, dict, dict_len);
+    int rc = inflate_core(src, src_len, work, dict_len, dict_len + dst_cap, res);
+    memcpy(dst, work + dict_len, res->out_len);
+    free(work);
+    return rc;
 }

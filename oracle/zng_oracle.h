@@ -105,6 +105,9 @@ typedef struct oracle_inflate_result {
 
 int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                        oracle_inflate_result *res);
+/* the same after inflateSetDictionary (inflate.c:1214-1261) */
+int oracle_inflate_raw_dict(const uint8_t *src, size_t src_len, const uint8_t *dict, size_t dict_len,
+                            uint8_t *dst, size_t dst_cap, oracle_inflate_result *res);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ _Static_assert(sizeof(zng_rocm_crc32_fold_t) == 68, "struct crc32_fold_s: uint8_
 _Static_assert(offsetof(zng_rocm_crc32_fold_t, fold) == 0, "fold first");
 _Static_assert(offsetof(zng_rocm_crc32_fold_t, value) == 64, "value after the 64-byte fold buffer");
 _Static_assert(sizeof(zng_rocm_check_row) == 16, "packed {adler, crc, len} row");
-_Static_assert(sizeof(zng_rocm_stream_job) == 24, "two pointers + two u32");
+_Static_assert(sizeof(zng_rocm_stream_job) == 32, "two pointers + four u32");
 
 /* the "CPU tier chosen so far": plain bytewise forms (adler32_c.c:11-54 / crc32_braid_p.h DO1 semantics) */
 static uint32_t cpu_adler(uint32_t adler, const uint8_t *buf, size_t len) {

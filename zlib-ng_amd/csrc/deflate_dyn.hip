@@ -591,14 +591,14 @@ void gather_segments_kernel(const SegJob *__restrict__ jobs, const uint32_t *__r
 constexpr uint32_t kMaxStored = 65535u;
 
 __global__ __launch_bounds__(256)
-void stored_kernel(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ out) {
+void stored_kernel(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict__ out, int final_block) {
     const size_t nblk = n ? (n + kMaxStored - 1) / kMaxStored : 1;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
     for (size_t k = gid; k < nblk; k += gsz) {
         const size_t left = n - k * kMaxStored;
         const uint32_t ln = left < kMaxStored ? (uint32_t)left : kMaxStored;
         uint8_t *h = out + k * (kMaxStored + 5u);
-        h[0] = k + 1 == nblk ? 1 : 0;                               // BFINAL, BTYPE = 00, padding bits
+        h[0] = (k + 1 == nblk && final_block) ? 1 : 0;              // BFINAL, BTYPE = 00, padding bits
         h[1] = (uint8_t)ln;
         h[2] = (uint8_t)(ln >> 8);
         h[3] = (uint8_t)~ln;
@@ -638,6 +638,11 @@ size_t zng_rocm_deflate_bound(size_t source_len) {
 
 int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
                          size_t *out_len, void *stream) {
+    return zng_rocm_deflate_block_dev(level, d_in, in_len, 0, 0, d_out, out_cap, out_len, stream);
+}
+
+int zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags,
+                               uint8_t *d_out, size_t out_cap, size_t *out_len, void *stream) {
     if (!ctx()) {
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
@@ -647,7 +652,12 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         set_error("level %d is outside 0..9", level);
         return ZNG_ROCM_EINVAL;
     }
-    if (in_len >= (1ull << 32) - kSegBytes) {
+    if (dict_len > kPrime || (flags & ~(uint32_t)(ZNG_ROCM_BLOCK_NOT_FINAL | ZNG_ROCM_BLOCK_SYNC_FLUSH))) {
+        set_error("dict_len above 32768 or unknown flags");
+        return ZNG_ROCM_EINVAL;
+    }
+    const bool final_block = (flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
+    if (in_len + dict_len >= (1ull << 32) - kSegBytes) {
         set_error("streams of 4 GiB and more are not supported by the 32-bit position format");
         return ZNG_ROCM_EINVAL;
     }
@@ -664,7 +674,8 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     // max_chain_length per level, deflate.c:142-168
     if (level == 0) {                                               // deflate_stored: no scratch, no host round trip
         const size_t nblk = in_len ? (in_len + kMaxStored - 1) / kMaxStored : 1;
-        const size_t total0 = in_len + 5 * nblk;
+        const bool marker = !final_block && (flags & ZNG_ROCM_BLOCK_SYNC_FLUSH);   // deflate.c:1064-1076
+        const size_t total0 = in_len + 5 * nblk + (marker ? 5 : 0);
         if (total0 > out_cap) {
             set_error("stored size %llu exceeds out_cap", (unsigned long long)total0);
             return -5;
@@ -673,8 +684,12 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
         unsigned grid = (unsigned)((pieces + 255) / 256);
         if (grid > 65536u) grid = 65536u;
         if (grid == 0) grid = 1;
-        ZR_LAUNCH_TRACED(stored_kernel, dim3(grid), dim3(256), st, d_in, in_len, d_out);
+        ZR_LAUNCH_TRACED(stored_kernel, dim3(grid), dim3(256), st, d_in, in_len, d_out, final_block ? 1 : 0);
         ZR_HIP(hipGetLastError());
+        if (marker) {
+            static const uint8_t empty_stored[5] = {0x00, 0x00, 0x00, 0xff, 0xff};
+            ZR_HIP(hipMemcpyAsync(d_out + in_len + 5 * nblk, empty_stored, 5, hipMemcpyHostToDevice, st));
+        }
         ZR_HIP(hipStreamSynchronize(st));
         *out_len = total0;
         return ZNG_ROCM_OK;
@@ -700,17 +715,18 @@ int zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t 
     if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
     if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * sizeof(uint32_t), false, (void **)&d_seg_len)) return rc;
     if (int rc = scratch_reserve(ws, kScrDynDstOff, nseg * sizeof(uint64_t), false, (void **)&d_dst_off)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynSel, (in_len + 1024) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSel, (in_len + dict_len + 1024 + 4) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
     size_t slot_total = 0;
     for (size_t i = 0; i < nseg; ++i) {
-        const uint32_t a = (uint32_t)(i * seg_bytes);
-        const uint32_t b = (uint32_t)((i + 1) * seg_bytes < in_len ? (i + 1) * seg_bytes : in_len);
-        jobs[i].in = d_in;
+        // positions count from the first dictionary byte: the segments' own 32 KiB priming reaches into it
+        const uint32_t a = dict_len + (uint32_t)(i * seg_bytes);
+        const uint32_t b = dict_len + (uint32_t)((i + 1) * seg_bytes < in_len ? (i + 1) * seg_bytes : in_len);
+        jobs[i].in = d_in - dict_len;
         jobs[i].seg_start = a;
         jobs[i].seg_end = b;
         jobs[i].out_cap = (uint32_t)seg_slot_bytes(b - a);
-        jobs[i].is_last = i + 1 == nseg;
-        jobs[i].sel_off = 0;
+        jobs[i].is_last = (i + 1 == nseg && final_block) ? 1 : 0;
+        jobs[i].sel_off = (4u - dict_len % 4u) % 4u;      // selector of a segment's first byte stays 16-byte aligned
         jobs[i].out = (uint8_t *)slot_total;          // offset for now
         slot_total += jobs[i].out_cap;
     }

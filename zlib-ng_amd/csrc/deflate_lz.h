@@ -92,6 +92,20 @@ __device__ __forceinline__ uint32_t lz_prefix16(const u32x4_unaligned &a, const 
     return l;
 }
 
+// A batch that only enters its positions into the hash (dictionary priming: deflateSetDictionary's
+// insert_string loop, deflate.c:499-515): the same wave-ordered exchange as lz_batch, nothing else.
+template <int HBITS, int NW = 4>
+__device__ __forceinline__ void lz_insert_batch(uint32_t n, uint32_t P, uint32_t first4, LzShared<HBITS> *sh, int t) {
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t p = P + (uint32_t)t;
+    const bool can = p + kLzMinMatch <= n;
+    const uint32_t h = lz_hash<HBITS>(first4);
+    for (int w = 0; w < NW; ++w) {
+        if (wave == w && can) (void)atomicExch(&sh->head[h], p + 1u);
+        __syncthreads();
+    }
+}
+
 // One batch of the level-1 class: a single chain-head probe per position (deflate_quick.c:89-97).
 // `own` = the 16 bytes at this lane's position (zero beyond the end of the stream).
 // FULL: the caller guarantees that every position of the batch has its whole 258-byte lookahead inside the stream

@@ -30,10 +30,12 @@ namespace zr {
 constexpr int kQuickHashBits = 12;      // 16 KiB head table: up to 8 streams in flight per CU (see deflate_lz.h)
 
 struct StreamJobDev {
-    const uint8_t *in;
+    const uint8_t *in;          // first byte of the dictionary (= the plaintext when there is none)
     uint8_t       *out;
-    uint32_t       in_len;
+    uint32_t       n;           // dictionary + plaintext bytes
     uint32_t       out_cap;
+    uint32_t       start;       // dictionary bytes: positions below `start` are entered into the hash, never emitted
+    uint32_t       flags;       // ZNG_ROCM_BLOCK_*
 };
 
 // ---- static Huffman (RFC 1951 3.2.6; the reference's static_ltree / static_dtree, trees_tbl.h) -----------
@@ -98,14 +100,23 @@ void deflate_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__res
 
     const StreamJobDev job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
-    const uint32_t n = job.in_len;
+    const uint32_t n = job.n, start = job.start;
+    const bool final_block = (job.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
     uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     for (int i = t; i < (1 << kQuickHashBits); i += 256) sh.lz.head[i] = 0;
-    for (int i = t; i < (int)kRingWords; i += 256) sh.ring[i] = i == 0 ? 3u : 0u;   // BFINAL = 1, BTYPE = 01 (deflate_quick.c:30-34)
-    if (t == 0) sh.lz.cover = 0;
+    // block header: BFINAL, BTYPE = 01 (deflate_quick.c:30-34 emits it through zng_tr_emit_tree(s, STATIC_TREES, last))
+    for (int i = t; i < (int)kRingWords; i += 256) sh.ring[i] = i == 0 ? (final_block ? 3u : 2u) : 0u;
+    if (t == 0) sh.lz.cover = start;     // nothing below the first plaintext byte is ever produced
     __syncthreads();
+
+    // dictionary priming: the whole batches below `start` only enter their positions into the hash
+    uint32_t P0 = 0;
+    for (; P0 + 256u <= start; P0 += 256u) {
+        const uint32_t p = P0 + (uint32_t)t;
+        lz_insert_batch<kQuickHashBits, 4>(n, P0, p + kLzMinMatch <= n ? load_u32(in + p) : 0u, &sh.lz, t);
+    }
 
     uint32_t cursor = 3;                 // bits placed so far (uniform over the workgroup)
     uint32_t flushed = 0;                // whole words already written to `out`
@@ -140,9 +151,9 @@ void deflate_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__res
         }
     };
 
-    u32x4_unaligned own = load_16_guarded(in, (uint32_t)t, n);       // this lane's 16 bytes of the current batch
+    u32x4_unaligned own = load_16_guarded(in, P0 + (uint32_t)t, n);  // this lane's 16 bytes of the current batch
     int parity = 0;
-    for (uint32_t P = 0; P < n; P += 256) {
+    for (uint32_t P = P0; P < n; P += 256) {
         // every position of the NEXT batch has its 16 bytes inside the stream / of this batch its whole lookahead
         const uint32_t pn = P + 256u + (uint32_t)t;
         const bool full = n >= 256u + kStdMaxMatch + 4u && P <= n - (256u + kStdMaxMatch + 4u);
@@ -156,8 +167,8 @@ void deflate_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__res
         flush(kFlushWords);
         if (have_pending) place(parity ^ 1);
         const uint32_t p = P + (uint32_t)t;
-        const uint32_t byte = own.x & 0xffu;                 // zero beyond the end of the stream
-        accA += byte;
+        const uint32_t byte = p >= start ? own.x & 0xffu : 0u;   // zero beyond the end of the stream; the dictionary
+        accA += byte;                                            // is not part of the checksum
         accB += (unsigned long long)(n - p) * byte;
         // both codes are computed and one is selected: no branch (lanes without a token carry r.len = r.dist = 0,
         // which the match coder turns into harmless garbage that the select drops)
@@ -207,11 +218,19 @@ void deflate_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__res
             cbits -= 32;
         }
         uint32_t bytes = wbase * 4u;
-        for (uint32_t k = 0; k < (cbits + 7u) / 8u; ++k) outb[bytes++] = (uint8_t)(cw >> (8 * k));
+        const bool sync = !final_block && (job.flags & ZNG_ROCM_BLOCK_SYNC_FLUSH) != 0;
+        if (sync) cbits += 3;                                // header of an empty stored block: BFINAL = 0, BTYPE = 00
+        for (uint32_t k = 0; k < (cbits + 7u) / 8u; ++k) outb[bytes++] = (uint8_t)((unsigned long long)cw >> (8 * k));   // up to 34 bits
+        if (sync) {                                          // ... byte aligned, LEN = 0, NLEN = 0xffff: what Z_SYNC_FLUSH
+            outb[bytes++] = 0x00;                            // appends (deflate.c:1064-1076, zng_tr_stored_block)
+            outb[bytes++] = 0x00;
+            outb[bytes++] = 0xff;
+            outb[bytes++] = 0xff;
+        }
         const unsigned long long A = (sh.red_a[0] + sh.red_a[1] + sh.red_a[2] + sh.red_a[3]) % kAdlerBase;
         const unsigned long long B = (sh.red_b[0] + sh.red_b[1] + sh.red_b[2] + sh.red_b[3]) % kAdlerBase;
         results[2 * blockIdx.x] = bytes;
-        results[2 * blockIdx.x + 1] = (uint32_t)(((1 + A) % kAdlerBase) | ((((unsigned long long)n + B) % kAdlerBase) << 16));
+        results[2 * blockIdx.x + 1] = (uint32_t)(((1 + A) % kAdlerBase) | ((((unsigned long long)(n - start) + B) % kAdlerBase) << 16));
     }
 }
 
@@ -225,7 +244,7 @@ size_t zng_rocm_deflate_quick_bound(size_t source_len) {
     // 3 header bits + at most 9 bits per input byte (a match of >= 4 bytes costs <= 31 bits) + 7 EOB bits,
     // cf. DEFLATE_QUICK_OVERHEAD / DEFLATE_BLOCK_OVERHEAD (zutil.h:71-79, deflate.c:773-777); rounded so that
     // consecutive streams stay 16-byte aligned.
-    size_t b = source_len + ((source_len + 7) >> 3) + 8;
+    size_t b = source_len + ((source_len + 7) >> 3) + 8 + 5;          // + the sync-flush terminator of a non-final block
     return (b + 15) & ~(size_t)15;
 }
 
@@ -250,13 +269,16 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     if (int rc = scratch_reserve(ws, kScrQuickJobsHost, njobs * sizeof(StreamJobDev), true, (void **)&h_jobs)) return rc;
     for (size_t i = 0; i < njobs; ++i) {
         const zng_rocm_stream_job &j = jobs[i];
-        if ((j.in_len && (!j.in || !j.out)) || ((uintptr_t)j.in & 15) || ((uintptr_t)j.out & 3) ||
-            j.out_cap < zng_rocm_deflate_quick_bound(j.in_len)) {
-            set_error("job %zu: streams must be 16-byte aligned (in), 4-byte aligned (out) and out_cap >= "
-                      "zng_rocm_deflate_quick_bound(in_len)", i);
+        if (!j.out || (j.in_len && !j.in) || ((uintptr_t)j.out & 3) || j.out_cap < zng_rocm_deflate_quick_bound(j.in_len)) {
+            set_error("job %zu: out must be 4-byte aligned and out_cap >= zng_rocm_deflate_quick_bound(in_len)", i);
             return ZNG_ROCM_EINVAL;
         }
-        h_jobs[i] = StreamJobDev{j.in, j.out, j.in_len, j.out_cap};
+        if (j.dict_len > 32768u || (uint64_t)j.in_len + j.dict_len > 0xffffffffull || (j.dict_len && !j.in) ||
+            (j.flags & ~(uint32_t)(ZNG_ROCM_BLOCK_NOT_FINAL | ZNG_ROCM_BLOCK_SYNC_FLUSH))) {
+            set_error("job %zu: dict_len above 32768, unknown flags, or dictionary + plaintext of 4 GiB and more", i);
+            return ZNG_ROCM_EINVAL;
+        }
+        h_jobs[i] = StreamJobDev{j.in - j.dict_len, j.out, j.in_len + j.dict_len, j.out_cap, j.dict_len, j.flags};
     }
     ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     if (int rc = host_tables_release(ws, st)) return rc;

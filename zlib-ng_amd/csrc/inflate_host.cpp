@@ -10,7 +10,8 @@
 //   length/distance base+extra tables               inftrees.c:52-65 (RFC 1951 3.2.5)
 //   64-bit refill, root tables of 10 (lit/len) and 9 (dist) bits   inffast_tpl.h:44-46,142-147; inflate.c:899,909
 // One-shot contract: the whole raw stream is in `src`; "invalid distance too far back" = distance
-// larger than the bytes produced so far (inffast_tpl.h:198-226 with no prior window).
+// larger than the bytes produced so far plus the `window_len` bytes of history the caller says precede the
+// stream (inffast_tpl.h:198-226; whave after inflateSetDictionary, inflate.c:1214-1261).
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -229,7 +230,7 @@ struct Bits {
 #define FAIL(m) do { t->status = Z_DATA_ERROR_; t->msg = (m); goto done; } while (0)
 #define STARVE() do { t->status = Z_BUF_ERROR_; t->msg = "input ended before the final block"; goto done; } while (0)
 
-int decode_stream(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *t) {
+int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_rocm_inflate_tokens *t) {
     Out o;
     o.t = t;
     o.tok_cap = o.lit_cap = o.seg_cap = 0;
@@ -424,7 +425,7 @@ int decode_stream(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *t
             b.drop(d.bits);
             unsigned dist = d.val + b.peek(xb);
             b.drop(xb);
-            if (dist > o.out_pos) FAIL("invalid distance too far back");
+            if (dist > o.out_pos + window_len) FAIL("invalid distance too far back");
             flush_run(o);
             maybe_new_segment(o);
             push_token(o, 0x80000000u | ((len - 3) << 16) | (dist - 1));
@@ -461,7 +462,14 @@ extern "C" {
 int zng_rocm_inflate_tokens_decode(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *out) {
     if (!out || (!src && src_len)) return ZNG_ROCM_EINVAL;
     memset(out, 0, sizeof(*out));
-    return decode_stream(src, src_len, out);
+    return decode_stream(src, src_len, 0, out);
+}
+
+int zng_rocm_inflate_tokens_decode_window(const uint8_t *src, size_t src_len, uint32_t window_len,
+                                          zng_rocm_inflate_tokens *out) {
+    if (!out || (!src && src_len) || window_len > 32768u) return ZNG_ROCM_EINVAL;
+    memset(out, 0, sizeof(*out));
+    return decode_stream(src, src_len, window_len, out);
 }
 
 void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t) {

@@ -160,12 +160,15 @@ __device__ __forceinline__ void tail_step(uint16_t *__restrict__ sym, long long 
     __syncthreads();
 }
 
-// grid.x = group.  Tails exist for segments 0 .. nsegs-2.
+// grid.x = group.  Tails exist for segments 0 .. nsegs-2.  With a prior window (the 32768 symbols in front of
+// sym[0] hold it) the first tail is resolved against that window first, so that group 0 ends in plain bytes.
 __global__ __launch_bounds__(1024)
-void inflate_context_group_kernel(const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
+void inflate_context_group_kernel(const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym,
+                                  int has_window) {
     const size_t first = (size_t)blockIdx.x * kGroup;
     size_t last = first + kGroup;
     if (last > nsegs - 1) last = nsegs - 1;
+    if (has_window && blockIdx.x == 0 && last > 0) tail_step(sym, (long long)segs[4], (long long)segs[1]);
     for (size_t s = first + 1; s < last; ++s)
         tail_step(sym, (long long)segs[3 * s + 4], (long long)segs[3 * s + 1]);
 }
@@ -178,6 +181,14 @@ void inflate_context_chain_kernel(const uint64_t *__restrict__ segs, size_t nseg
         if (last > nsegs - 1) last = nsegs - 1;
         tail_step(sym, (long long)segs[3 * (last - 1) + 4], (long long)segs[3 * first + 1]);
     }
+}
+
+// the symbols in front of sym[0]: the caller's window, right-aligned to the stream's first byte (zeros before it)
+__global__ __launch_bounds__(256)
+void inflate_window_kernel(const uint8_t *__restrict__ window, uint32_t window_len, uint16_t *__restrict__ sym) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;            // 0 .. 32767
+    const uint32_t gap = (uint32_t)kCtx - window_len;
+    sym[(long long)k - kCtx] = k >= gap ? (uint16_t)window[k - gap] : (uint16_t)0;
 }
 
 // K3.  grid.x = segment
@@ -212,6 +223,34 @@ using namespace zr;
 
 extern "C" {
 
+static int resolve_impl(const uint32_t *d_tokens, const uint8_t *d_literals, size_t nliterals, const uint64_t *d_segs,
+                        size_t nsegs, uint16_t *sym, uint8_t *d_out, uint64_t out_len, const uint8_t *d_window,
+                        uint32_t window_len, bool has_window, hipStream_t st) {
+    if (out_len == 0 || nsegs == 0) return ZNG_ROCM_OK;
+    if (!d_tokens || !d_segs || !sym || !d_out) return ZNG_ROCM_EINVAL;
+    if (has_window) {
+        if (window_len > (uint32_t)kCtx || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
+        hipLaunchKernelGGL(inflate_window_kernel, dim3((unsigned)(kCtx / 256)), dim3(256), 0, st, d_window, window_len, sym);
+        ZR_HIP(hipGetLastError());
+    }
+    ZR_LAUNCH_TRACED(inflate_segments_kernel, dim3((unsigned)((nsegs + 3) / 4)), dim3(256), st, d_tokens, d_literals,
+                     nliterals, d_segs, nsegs, sym);
+    ZR_HIP(hipGetLastError());
+    if (nsegs > 1) {
+        const unsigned ngroups = (unsigned)((nsegs - 1 + kGroup - 1) / kGroup);
+        hipLaunchKernelGGL(inflate_context_group_kernel, dim3(ngroups), dim3(1024), 0, st, d_segs, nsegs, sym,
+                           has_window ? 1 : 0);
+        ZR_HIP(hipGetLastError());
+        if (ngroups > 1) {
+            hipLaunchKernelGGL(inflate_context_chain_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, sym);
+            ZR_HIP(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, sym, d_out);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
 int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
                                  size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
                                  uint8_t *d_out, uint64_t out_len, void *stream) {
@@ -221,26 +260,27 @@ int zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const
     }
     DeviceGuard dev;
     (void)ntokens;
-    if (out_len == 0 || nsegs == 0) return ZNG_ROCM_OK;
-    if (!d_tokens || !d_segs || !d_symbols || !d_out) return ZNG_ROCM_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(inflate_segments_kernel, dim3((unsigned)((nsegs + 3) / 4)), dim3(256), 0, st, d_tokens,
-                       d_literals, nliterals, d_segs, nsegs, d_symbols);
-    ZR_HIP(hipGetLastError());
-    if (nsegs > 1) {
-        const unsigned ngroups = (unsigned)((nsegs - 1 + kGroup - 1) / kGroup);
-        hipLaunchKernelGGL(inflate_context_group_kernel, dim3(ngroups), dim3(1024), 0, st, d_segs, nsegs, d_symbols);
-        ZR_HIP(hipGetLastError());
-        if (ngroups > 1) {
-            hipLaunchKernelGGL(inflate_context_chain_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, d_symbols);
-            ZR_HIP(hipGetLastError());
-        }
-    }
-    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, d_symbols,
-                       d_out);
-    ZR_HIP(hipGetLastError());
-    return ZNG_ROCM_OK;
+    return resolve_impl(d_tokens, d_literals, nliterals, d_segs, nsegs, d_symbols, d_out, out_len, nullptr, 0, false,
+                        (hipStream_t)stream);
 }
+
+int zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
+                                        size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
+                                        uint8_t *d_out, uint64_t out_len, const uint8_t *d_window,
+                                        uint32_t window_len, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    DeviceGuard dev;
+    (void)ntokens;
+    if (!d_symbols) return ZNG_ROCM_EINVAL;
+    return resolve_impl(d_tokens, d_literals, nliterals, d_segs, nsegs, d_symbols + kCtx, d_out, out_len, d_window,
+                        window_len, true, (hipStream_t)stream);
+}
+
+int zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
 int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                             size_t *in_used, void *stream);
@@ -253,14 +293,22 @@ int zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, siz
 // same, also reporting how many input bytes the stream occupied (the framing front ends find the trailer there)
 int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                             size_t *in_used, void *stream) {
+    return zng_rocm_inflate_raw_window(src, src_len, nullptr, 0, d_dst, dst_cap, out_len, in_used, stream);
+}
+
+// ... and with `window_len` bytes of history (device resident) in front of the stream: a preset dictionary
+// (inflateSetDictionary on a raw stream, inflate.c:1214-1261) or the tail of what an earlier call produced
+int zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream) {
     if (!ctx()) {
         set_error("zng_rocm_init() has not succeeded");
         return ZNG_ROCM_ENODEV;
     }
     DeviceGuard dev;
+    if (window_len > (uint32_t)kCtx || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     zng_rocm_inflate_tokens tk;
-    int status = zng_rocm_inflate_tokens_decode(src, src_len, &tk);
+    int status = zng_rocm_inflate_tokens_decode_window(src, src_len, window_len, &tk);
     if (out_len) *out_len = tk.out_len;
     if (in_used) *in_used = tk.in_used;
     if (status == -4) {
@@ -279,7 +327,7 @@ int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, 
         const size_t tok_b = (tk.ntokens * 4 + 255) & ~(size_t)255;
         const size_t seg_b = ((tk.nsegs + 1) * 24 + 255) & ~(size_t)255;
         const size_t lit_b = (tk.nliterals + 255) & ~(size_t)255;
-        const size_t sym_b = (size_t)tk.out_len * 2;
+        const size_t sym_b = ((size_t)tk.out_len + (size_t)kCtx) * 2;          // + the window's symbols in front
         uint8_t *d = nullptr;
         if (hipMalloc(&d, tok_b + seg_b + lit_b + sym_b) != hipSuccess) {
             zng_rocm_inflate_tokens_free(&tk);
@@ -294,9 +342,10 @@ int zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst, 
             set_error("H2D of the token stream failed: %s", hipGetErrorString(e));
             rc = ZNG_ROCM_EHIP;
         } else {
-            rc = zng_rocm_inflate_resolve_dev((const uint32_t *)d, tk.ntokens, d + tok_b + seg_b, tk.nliterals,
-                                              (const uint64_t *)(d + tok_b), tk.nsegs,
-                                              (uint16_t *)(d + tok_b + seg_b + lit_b), d_dst, tk.out_len, st);
+            rc = zng_rocm_inflate_resolve_window_dev((const uint32_t *)d, tk.ntokens, d + tok_b + seg_b, tk.nliterals,
+                                                     (const uint64_t *)(d + tok_b), tk.nsegs,
+                                                     (uint16_t *)(d + tok_b + seg_b + lit_b), d_dst, tk.out_len,
+                                                     d_window, window_len, st);
         }
         // the host buffers and the device workspace are released after the stream drained
         if (hipStreamSynchronize(st) != hipSuccess && rc == ZNG_ROCM_OK) {

@@ -10,7 +10,11 @@ from . import rocm
 
 class StreamJob(C.Structure):
     """zng_rocm_stream_job"""
-    _fields_ = [("in_ptr", C.c_void_p), ("out_ptr", C.c_void_p), ("in_len", C.c_uint32), ("out_cap", C.c_uint32)]
+    _fields_ = [("in_ptr", C.c_void_p), ("out_ptr", C.c_void_p), ("in_len", C.c_uint32), ("out_cap", C.c_uint32),
+                ("dict_len", C.c_uint32), ("flags", C.c_uint32)]
+
+
+BLOCK_NOT_FINAL, BLOCK_SYNC_FLUSH = 1, 2
 
 
 def deflate_quick_bound(n):
@@ -26,7 +30,8 @@ class QuickBatch:
     CUDA tensor [n, 2] = {compressed length, adler32 of the input}.
     """
 
-    def __init__(self, src, in_off, in_len):
+    def __init__(self, src, in_off, in_len, dict_len=None, flags=None):
+        """dict_len[i] bytes in front of stream i (inside `src`) prime its hash; flags[i] = BLOCK_* bits"""
         import torch
         rocm._need_init()
         self.src = src
@@ -44,8 +49,10 @@ class QuickBatch:
         jobs = (StreamJob * self.n)()
         base_in, base_out = src.data_ptr(), self.dst.data_ptr()
         for i in range(self.n):
-            if self.in_off[i] % 16:
-                raise ValueError("stream offsets must be multiples of 16")
+            jobs[i].dict_len = 0 if dict_len is None else int(dict_len[i])
+            jobs[i].flags = 0 if flags is None else int(flags[i])
+            if jobs[i].dict_len > self.in_off[i]:
+                raise ValueError("the dictionary must lie inside src, in front of the stream")
             jobs[i].in_ptr = base_in + self.in_off[i]
             jobs[i].out_ptr = base_out + self.out_off[i]
             jobs[i].in_len = self.in_len[i]
@@ -69,16 +76,17 @@ def deflate_bound(n):
     return rocm.lib().zng_rocm_deflate_bound(n)
 
 
-def deflate_dev(src, level=6, length=None, offset=0, stream=None):
-    """one large device-resident stream -> (uint8 CUDA tensor with the raw deflate stream, compressed length).
-    level 2..9 (chain-walking levels; level 1 is QuickBatch)."""
+def deflate_dev(src, level=6, length=None, offset=0, stream=None, dict_len=0, flags=0):
+    """one large device-resident stream (or, with dict_len / flags, one BLOCK of a longer stream whose dict_len
+    bytes of history sit in src in front of `offset`) -> (uint8 CUDA tensor with raw deflate, compressed length).
+    level 0 = stored, 1 = single probe, 2..9 = chain walk."""
     import torch
     rocm._need_init()
     n = src.numel() - offset if length is None else length
     cap = deflate_bound(n)
     dst = torch.empty(cap, dtype=torch.uint8, device=src.device)
     out_len = C.c_size_t(0)
-    rc = rocm.lib().zng_rocm_deflate_dev(level, rocm._dev_ptr(src, offset), n, rocm._dev_ptr(dst), cap,
-                                         C.byref(out_len), rocm._stream_ptr(stream))
-    rocm._check(rc, "zng_rocm_deflate_dev")
+    rc = rocm.lib().zng_rocm_deflate_block_dev(level, rocm._dev_ptr(src, offset), n, dict_len, flags, rocm._dev_ptr(dst),
+                                               cap, C.byref(out_len), rocm._stream_ptr(stream))
+    rocm._check(rc, "zng_rocm_deflate_block_dev")
     return dst, out_len.value

@@ -22,13 +22,13 @@ class InflateTokens(C.Structure):
 class DecodedStream:
     """numpy views of one decoded stream (copies; the C buffers are freed immediately)"""
 
-    def __init__(self, src):
+    def __init__(self, src, window_len=0):
         import numpy as np
         lib = rocm.lib()
         raw = bytes(src)
         buf = C.create_string_buffer(raw, max(len(raw), 1))
         tk = InflateTokens()
-        self.status = lib.zng_rocm_inflate_tokens_decode(C.addressof(buf), len(raw), C.byref(tk))
+        self.status = lib.zng_rocm_inflate_tokens_decode_window(C.addressof(buf), len(raw), window_len, C.byref(tk))
         self.msg = (tk.msg or b"").decode()
         self.out_len = tk.out_len
         self.in_used = tk.in_used
@@ -43,8 +43,8 @@ class DecodedStream:
         lib.zng_rocm_inflate_tokens_free(C.byref(tk))
 
 
-def decode_tokens(src):
-    return DecodedStream(src)
+def decode_tokens(src, window_len=0):
+    return DecodedStream(src, window_len)
 
 
 def resolve_dev(dec, stream=None):
@@ -78,3 +78,17 @@ def inflate_raw(src, dst, stream=None):
     rc = rocm.lib().zng_rocm_inflate_raw(C.addressof(buf), len(raw), rocm._dev_ptr(dst), dst.numel(),
                                          C.byref(produced), rocm._stream_ptr(stream))
     return rc, produced.value
+
+
+def inflate_raw_window(src, window, dst, stream=None):
+    """one-shot raw inflate of a stream that continues `window` (uint8 CUDA tensor, <= 32768 bytes: a preset
+    dictionary or the tail of earlier output); returns (zlib status, bytes produced, input bytes used)"""
+    rocm._need_init()
+    raw = bytes(src)
+    buf = C.create_string_buffer(raw, max(len(raw), 1))
+    produced, used = C.c_uint64(0), C.c_size_t(0)
+    wl = 0 if window is None else window.numel()
+    rc = rocm.lib().zng_rocm_inflate_raw_window(C.addressof(buf), len(raw), None if not wl else rocm._dev_ptr(window), wl,
+                                                rocm._dev_ptr(dst), dst.numel(), C.byref(produced), C.byref(used),
+                                                rocm._stream_ptr(stream))
+    return rc, produced.value, used.value

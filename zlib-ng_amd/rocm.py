@@ -79,9 +79,16 @@ _PROTOS = {
     "zng_rocm_deflate_bound": (C.c_size_t, [C.c_size_t]),
     "zng_rocm_deflate_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t), C.c_void_p]),
+    "zng_rocm_deflate_block_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                             C.POINTER(C.c_size_t), C.c_void_p]),
     "zng_rocm_deflate_quick_bound": (C.c_size_t, [C.c_size_t]),
     "zng_rocm_deflate_quick_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_inflate_tokens_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zng_rocm_inflate_tokens_decode_window": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "zng_rocm_inflate_resolve_window_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                      C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zng_rocm_inflate_raw_window": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_void_p]),
     "zng_rocm_inflate_tokens_free": (None, [C.c_void_p]),
     "zng_rocm_inflate_resolve_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
