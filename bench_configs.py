@@ -244,6 +244,28 @@ def main():
             "cpu_python_zlib_inflate_out_MBps_1thread": round(n / 1e6 / t_pyinf, 1),
             "cpu_python_zlib_deflate6_in_MBps_1thread": round(n / 1e6 / t_comp, 1)}
         del d_tok, d_lit, d_seg, d_sym, d_out, dst
+        # many independent streams (the pigz shape): the same 256 MiB as 64 streams of 4 MiB, each compressed by the
+        # device's own level-6 class (validated in cfg4), decoded on T host threads, resolved per stream on the device
+        each = n // 64
+        d_plain = torch.from_numpy(plain).cuda()
+        parts = []
+        for k in range(64):
+            dstk, clk = dfl.deflate_dev(d_plain, level=6, length=each, offset=k * each)
+            parts.append(dstk[:clk].cpu().numpy().tobytes())
+        outs = [torch.empty(each + 64, dtype=torch.uint8, device="cuda") for _ in range(64)]
+        many = {}
+        prepared = inf.InflateBatch(parts, outs)
+        for T in (1, 4, 16, min(64, os.cpu_count() or 1)):
+            prepared.run(T)                                                  # warm: the pooled worker resources
+            t0 = time.perf_counter()
+            res = prepared.run(T)
+            dt = time.perf_counter() - t0
+            ok_m = all(r[0] == 1 and r[1] == each for r in res) and all(
+                torch.equal(outs[k][:each], d_plain[k * each:(k + 1) * each]) for k in (0, 17, 63))
+            many["threads_%d" % T] = {"out_GBps": round(n / 1e9 / dt, 2), "in_GBps": round(sum(map(len, parts)) / 1e9 / dt, 2),
+                                      "bit_exact_sample": bool(ok_m)}
+        report["cfg3"]["many_streams_64x%dMiB" % (each >> 20)] = many
+        del outs, d_plain
 
     # ---- cfg4: deflate level 6 of one 256 MiB stream -----------------------------------------------------
     if want("cfg4"):

@@ -318,6 +318,25 @@ int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst,
 int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                  uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
+/* Many independent raw streams at once: `nthreads` host threads (<= 0: one per hardware thread) take the jobs in
+ * order, each decoding on the host and resolving on the device on its own HIP stream, so that the sequential decode
+ * -- where an inflate spends its time -- runs on all the cores the caller allows while the device work of one stream
+ * overlaps the decode of the next (the pigz shape: test/pigz/CMakeLists.txt).  Per job: `src` host, `d_dst` device
+ * (dst_cap bytes), an optional device-resident window / dictionary in front (as zng_rocm_inflate_raw_window); on
+ * return `status` is the job's zlib status (1 = Z_STREAM_END, -3 with the reference's text in `msg`, -5 input ended
+ * early or destination too small, negative ZNG_ROCM_E*), `out_len` / `in_used` as in the one-shot call.  Synchronous:
+ * every plaintext is in place when the call returns.  The return value is 0 or the first device error. */
+typedef struct zng_rocm_inflate_job {
+    const uint8_t *src;       size_t   src_len;
+    uint8_t       *d_dst;     size_t   dst_cap;
+    const uint8_t *d_window;  uint32_t window_len;
+    int            status;
+    uint64_t       out_len;
+    size_t         in_used;
+    const char    *msg;
+} zng_rocm_inflate_job;
+int  zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthreads);
+
 /* ---- compress2 / uncompress2 class front ends (compress.c:31-98, uncompr.c:25-76) ---------------------
  * `format`: 0 = raw deflate, 1 = zlib (RFC 1950), 2 = gzip (RFC 1952).  The trailer checksum (Adler-32 /
  * CRC-32 + ISIZE) is computed by the device checksum kernel over the device-resident plaintext.

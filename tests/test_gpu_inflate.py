@@ -153,3 +153,52 @@ def test_output_beyond_4gib(inf):
     zr.adler32_crc32_dev(out, chk, adler=1, crc=0, length=total)
     assert [v & 0xffffffff for v in chk.tolist()] == [adler, crc]
     assert out[-len(tail):].cpu().numpy().tobytes() == tail
+
+
+def test_inflate_many_threads(inf):
+    """zng_rocm_inflate_many: independent streams decoded on several host threads, each resolved on its own HIP
+    stream (the pigz shape).  Mixed bag on purpose: empty, tiny, multi-segment, stored, a preset dictionary, a
+    corrupted stream, a truncated one and a destination that is too small -- every job reports its own status, and
+    the result does not depend on the number of threads."""
+    torch = torch_mod()
+    rng = np.random.default_rng(1234)
+    mix = synth.silesia_like(24 << 20, seed=77, seg_bytes=1 << 20).tobytes()
+    plains = [b"", b"x", mix[:70000], mix[1 << 20:(1 << 20) + (5 << 20)], bytes(rng.integers(0, 256, size=300000, dtype=np.uint8)),
+              mix[7 << 20:(7 << 20) + (3 << 20)], mix[11 << 20:(11 << 20) + 1234567], b"ab" * 400000]
+    plains += [mix[(12 + k) << 20:(13 + k) << 20] for k in range(10)]
+    streams, windows, expect = [], [], []
+    for i, p in enumerate(plains):
+        streams.append(_raw_deflate(p, 1 + i % 9))
+        windows.append(None)
+        expect.append((1, p))
+    dictionary = mix[:32768]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=dictionary)
+    streams.append(c.compress(mix[40000:900000]) + c.flush())
+    windows.append(torch.from_numpy(np.frombuffer(dictionary, dtype=np.uint8).copy()).cuda())
+    expect.append((1, mix[40000:900000]))
+    bad = bytearray(streams[3])
+    bad[len(bad) // 2] ^= 0x10
+    ost, omsg, oout, _ = inflate_util.oracle_inflate(bytes(bad), cap=8 << 20)
+    streams.append(bytes(bad))
+    windows.append(None)
+    expect.append((ost, oout))
+    streams.append(streams[5][:len(streams[5]) // 3])                    # truncated
+    windows.append(None)
+    expect.append((-5, None))
+    dsts = [torch.zeros(max(len(e[1]) if e[1] is not None else 4 << 20, 1) + 64, dtype=torch.uint8, device="cuda")
+            for e in expect]
+    streams.append(streams[2])                                           # destination too small
+    windows.append(None)
+    expect.append((-5, None))
+    dsts.append(torch.zeros(1000, dtype=torch.uint8, device="cuda"))
+    for nthreads in (1, 3, 8):
+        for d in dsts:
+            d.zero_()
+        res = inf.inflate_many(streams, dsts, windows, nthreads=nthreads)
+        for i, ((st, want), (got_st, out_len, in_used, msg)) in enumerate(zip(expect, res)):
+            assert got_st == st, (nthreads, i, got_st, st, msg)
+            if st == 1:
+                assert out_len == len(want) and in_used == len(streams[i])
+                assert dsts[i][:out_len].cpu().numpy().tobytes() == want, (nthreads, i)
+            elif st == -3:
+                assert msg == omsg and dsts[i][:out_len].cpu().numpy().tobytes() == want

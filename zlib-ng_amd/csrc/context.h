@@ -131,6 +131,7 @@ struct DeviceGuard {
 };
 
 void checksum_reset_reserved_cus();        // checksum.hip
+void inflate_pool_shutdown();              // inflate_many.hip: pooled worker resources
 
 // checksum.hip: one streaming pass (+ finalize) over device-resident bytes.  d_dst != nullptr = fold_copy.  When a
 // d_seed_* pointer is given, that checksum's seed is read ON THE DEVICE from it at finalize time (the word an earlier

@@ -291,6 +291,7 @@ int zng_rocm_shutdown(void) {
     if (!c) return ZNG_ROCM_OK;
     DeviceGuard dev;
     (void)hipDeviceSynchronize();
+    inflate_pool_shutdown();
     {
         std::lock_guard<std::mutex> lk(g_tr_mu);
         g_tr_on.store(false);

@@ -148,8 +148,14 @@ int build_table(TableKind kind, const uint16_t *lens, int n, int root, Ent *tabl
     return 0;
 }
 
+// (re)allocation of the three token-stream arrays: plain realloc, or the pinned-memory form the batched inflate
+// passes in (its workers keep their arrays across streams and hand them to the DMA engine without a staging copy)
+typedef void *(*ReallocFn)(void *old, size_t old_bytes, size_t new_bytes);
+static void *plain_realloc(void *old, size_t, size_t new_bytes) { return realloc(old, new_bytes); }
+
 struct Out {
     zng_rocm_inflate_tokens *t;
+    ReallocFn re;
     size_t tok_cap, lit_cap, seg_cap;
     uint64_t out_pos;           // bytes the stream has produced
     uint64_t seg_out;           // out_pos at which the current segment started
@@ -160,11 +166,11 @@ struct Out {
 constexpr uint64_t kSegTarget = 32u << 10;     // a segment closes once it holds >= 32 KiB of output
 constexpr uint32_t kMaxRun = 0x7fffffffu;
 
-inline void grow(void **p, size_t *cap, size_t need, size_t elt, bool *oom) {
+inline void grow(ReallocFn re, void **p, size_t *cap, size_t need, size_t elt, bool *oom) {
     if (need <= *cap) return;
     size_t ncap = *cap ? *cap : 4096;
     while (ncap < need) ncap += ncap >> 1;
-    void *q = realloc(*p, ncap * elt);
+    void *q = re(*p, *cap * elt, ncap * elt);
     if (!q) { *oom = true; return; }
     *p = q;
     *cap = ncap;
@@ -172,7 +178,7 @@ inline void grow(void **p, size_t *cap, size_t need, size_t elt, bool *oom) {
 
 inline void push_token(Out &o, uint32_t tok) {
     zng_rocm_inflate_tokens *t = o.t;
-    if (t->ntokens + 1 > o.tok_cap) grow((void **)&t->tokens, &o.tok_cap, t->ntokens + 1, 4, &o.oom);
+    if (t->ntokens + 1 > o.tok_cap) grow(o.re, (void **)&t->tokens, &o.tok_cap, t->ntokens + 1, 4, &o.oom);
     if (!o.oom) t->tokens[t->ntokens++] = tok;
 }
 
@@ -187,7 +193,7 @@ inline void maybe_new_segment(Out &o) {
     // only called at a token boundary (run == 0)
     if (o.out_pos - o.seg_out >= kSegTarget) {
         zng_rocm_inflate_tokens *t = o.t;
-        if ((t->nsegs + 2) * 3 > o.seg_cap) grow((void **)&t->segs, &o.seg_cap, (t->nsegs + 2) * 3, 8, &o.oom);
+        if ((t->nsegs + 2) * 3 > o.seg_cap) grow(o.re, (void **)&t->segs, &o.seg_cap, (t->nsegs + 2) * 3, 8, &o.oom);
         if (o.oom) return;
         uint64_t *s = t->segs + 3 * t->nsegs++;
         s[0] = t->ntokens;
@@ -199,7 +205,7 @@ inline void maybe_new_segment(Out &o) {
 
 inline void reserve_literals(Out &o, size_t more) {
     zng_rocm_inflate_tokens *t = o.t;
-    if (t->nliterals + more > o.lit_cap) grow((void **)&t->literals, &o.lit_cap, t->nliterals + more, 1, &o.oom);
+    if (t->nliterals + more > o.lit_cap) grow(o.re, (void **)&t->literals, &o.lit_cap, t->nliterals + more, 1, &o.oom);
 }
 
 struct Bits {
@@ -230,10 +236,19 @@ struct Bits {
 #define FAIL(m) do { t->status = Z_DATA_ERROR_; t->msg = (m); goto done; } while (0)
 #define STARVE() do { t->status = Z_BUF_ERROR_; t->msg = "input ended before the final block"; goto done; } while (0)
 
-int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_rocm_inflate_tokens *t) {
+// caps: capacities (in elements: tokens, literal bytes, seg words) of the arrays `t` already owns; updated on return
+int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_rocm_inflate_tokens *t,
+                  ReallocFn re = plain_realloc, size_t *caps = nullptr) {
     Out o;
     o.t = t;
-    o.tok_cap = o.lit_cap = o.seg_cap = 0;
+    o.re = re;
+    o.tok_cap = caps ? caps[0] : 0;
+    o.lit_cap = caps ? caps[1] : 0;
+    o.seg_cap = caps ? caps[2] : 0;
+    struct SaveCaps {                    // every exit path hands the capacities back
+        Out &o; size_t *caps;
+        ~SaveCaps() { if (caps) { caps[0] = o.tok_cap; caps[1] = o.lit_cap; caps[2] = o.seg_cap; } }
+    } save{o, caps};
     o.out_pos = o.seg_out = 0;
     o.run = 0;
     o.oom = false;
@@ -245,12 +260,12 @@ int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_r
     bool last = false;
 
     // segment 0
-    grow((void **)&t->segs, &o.seg_cap, 6, 8, &o.oom);
+    grow(o.re, (void **)&t->segs, &o.seg_cap, 6, 8, &o.oom);
     if (o.oom) goto oom;
     t->segs[0] = t->segs[1] = t->segs[2] = 0;
     t->nsegs = 1;
-    grow((void **)&t->tokens, &o.tok_cap, src_len / 2 + 1024, 4, &o.oom);
-    grow((void **)&t->literals, &o.lit_cap, src_len + 4096, 1, &o.oom);
+    grow(o.re, (void **)&t->tokens, &o.tok_cap, src_len / 2 + 1024, 4, &o.oom);
+    grow(o.re, (void **)&t->literals, &o.lit_cap, src_len + 4096, 1, &o.oom);
     if (o.oom) goto oom;
     t->status = Z_OK_;
     t->msg = "";
@@ -439,7 +454,7 @@ done:
     if (o.oom) goto oom;
     {
         // terminal triple
-        if ((t->nsegs + 1) * 3 > o.seg_cap) grow((void **)&t->segs, &o.seg_cap, (t->nsegs + 1) * 3, 8, &o.oom);
+        if ((t->nsegs + 1) * 3 > o.seg_cap) grow(o.re, (void **)&t->segs, &o.seg_cap, (t->nsegs + 1) * 3, 8, &o.oom);
         if (o.oom) goto oom;
         uint64_t *s = t->segs + 3 * t->nsegs;
         s[0] = t->ntokens;
@@ -456,6 +471,18 @@ oom:
 }
 
 }  // namespace
+
+// internal (inflate_many.hip): decode into arrays the caller keeps across streams -- `t`'s pointers and `caps` are
+// carried over, its counters are reset; arrays grow through `re`
+int zr_inflate_decode_reuse(const uint8_t *src, size_t src_len, uint32_t window_len, zng_rocm_inflate_tokens *t,
+                            size_t caps[3], void *(*re)(void *, size_t, size_t)) {
+    t->ntokens = t->nliterals = t->nsegs = 0;
+    t->out_len = 0;
+    t->in_used = 0;
+    t->status = 0;
+    t->msg = "";
+    return decode_stream(src, src_len, window_len, t, re, caps);
+}
 
 extern "C" {
 

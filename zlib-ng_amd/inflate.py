@@ -92,3 +92,41 @@ def inflate_raw_window(src, window, dst, stream=None):
                                                 rocm._dev_ptr(dst), dst.numel(), C.byref(produced), C.byref(used),
                                                 rocm._stream_ptr(stream))
     return rc, produced.value, used.value
+
+
+class InflateJob(C.Structure):
+    """zng_rocm_inflate_job"""
+    _fields_ = [("src", C.c_void_p), ("src_len", C.c_size_t), ("d_dst", C.c_void_p), ("dst_cap", C.c_size_t),
+                ("d_window", C.c_void_p), ("window_len", C.c_uint32), ("status", C.c_int), ("out_len", C.c_uint64),
+                ("in_used", C.c_size_t), ("msg", C.c_char_p)]
+
+
+class InflateBatch:
+    """a prepared zng_rocm_inflate_many call: the job array and the host copies of the streams are built once"""
+
+    def __init__(self, streams, dsts, windows=None):
+        rocm._need_init()
+        self.n = len(streams)
+        self._keep = [C.create_string_buffer(bytes(s), max(len(s), 1)) for s in streams]
+        self._dsts, self._windows = dsts, windows
+        self.jobs = (InflateJob * self.n)()
+        for i in range(self.n):
+            self.jobs[i].src = C.addressof(self._keep[i])
+            self.jobs[i].src_len = len(streams[i])
+            self.jobs[i].d_dst = dsts[i].data_ptr()
+            self.jobs[i].dst_cap = dsts[i].numel()
+            w = None if windows is None else windows[i]
+            self.jobs[i].d_window = None if w is None or not w.numel() else w.data_ptr()
+            self.jobs[i].window_len = 0 if w is None else w.numel()
+
+    def run(self, nthreads=0):
+        rc = rocm.lib().zng_rocm_inflate_many(C.byref(self.jobs), self.n, nthreads)
+        rocm._check(rc, "zng_rocm_inflate_many")
+        return [(self.jobs[i].status, self.jobs[i].out_len, self.jobs[i].in_used, (self.jobs[i].msg or b"").decode())
+                for i in range(self.n)]
+
+
+def inflate_many(streams, dsts, windows=None, nthreads=0):
+    """streams: list of bytes-like raw deflate streams (host); dsts: list of uint8 CUDA tensors; windows: optional list
+    of uint8 CUDA tensors (or None) holding each stream's history.  Returns [(status, out_len, in_used, msg), ...]."""
+    return InflateBatch(streams, dsts, windows).run(nthreads)
