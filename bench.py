@@ -36,7 +36,7 @@ SEED = 0x5EED0002
 # 6.10 TB/s over the first ~100).  The settle phase below is UNTIMED and disclosed in the line (`settle_launches`):
 # it runs before the W warm-up steps, so `--warmup 5` measures the same steady state a long warm-up does.
 SETTLE_LAUNCHES = 300
-TRACE_STRIDE = 8                # HIP-event pairs bracket every 8th launch of the timed loop, not every launch
+TRACE_STRIDE = 8                # every 8th launch of the timed loop carries dispatch-attached HIP events (its own start / stop)
 
 # the REAL reference (zlib-ng 2.2.2, cmake build, runtime dispatch to AVX-512 VNNI /
 # VPCLMULQDQ), measured in the survey container on one thread -- quoted for context, not measured by this script
@@ -255,7 +255,7 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
         "exchange": "all_gather of %d B per rank (24 B per stream) + exclusive scan of clen on every rank; inside "
                     "ms_per_step, also timed alone here" % (per * 24),
         "parallelism": "streams/%d+allgather(24B/stream)" % world, "rehearsal_same_gpu": rehearse,
-        "roofline": {"bound": "hbm", "kernel": "zr::lz_parse_kernel (LZ77 front end of the level-1 class, DESIGN.md 3.4)",
+        "roofline": {"bound": "hbm", "kernel": "zr::deflate_quick_kernel (level-1 class: LZ77 parse with the static-Huffman emit fused in, DESIGN.md 3.5)",
                      "achieved": round(local_bytes / 1e9 / (k_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
@@ -277,7 +277,20 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     return out
 
 
+def emit(line):
+    """the ONE JSON line goes to the process's real stdout; everything else any library prints there (RCCL's
+    version banner at communicator creation, for one) was pointed at stderr when main() started"""
+    os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -339,7 +352,7 @@ def main():
                     "roofline": s["roofline"], "exchange_us": s["exchange_us"]}
             if "cpu_baseline" in s:
                 line["cpu_baseline"] = s["cpu_baseline"]
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -551,7 +564,7 @@ def main():
         if rank == 0:
             line["streams"] = s
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
 
     if world > 1 or force_dist:
         dist.barrier()

@@ -53,7 +53,13 @@ def main():
     zr.init(0)
     orc = oracle_lib.load()
     ref_crc = oracle_lib.load_ref_crc32()
-    report = {"device": torch.cuda.get_device_name(0), "host_cpus": os.cpu_count()}
+    report = {"device": torch.cuda.get_device_name(0), "host_cpus": os.cpu_count(),
+              "reference_container": {
+                  "what": "the REAL reference (zlib-ng 2.2.2, cmake build, AVX-512 dispatch), 1 thread, survey container, "
+                          "BASELINE.md section 2 -- quoted beside the CPython-zlib figures below, which are classic zlib "
+                          "1.2.11 (slower than zlib-ng) timed on this box; zlib-ng itself cannot be built under the round rules",
+                  "adler32_GBps": 7.5, "crc32_GBps": 9.8, "deflate_level1_MBps": 171, "deflate_level1_ratio": 1.91,
+                  "deflate_level6_MBps": 44, "deflate_level6_ratio": 2.94, "inflate_out_MBps": [318, 516]}}
     want = lambda name: not args.only or args.only == name
 
     # ---- cfg1: zng_adler32 over 64 MiB, CPU plumbing + bit-exact check --------------------------------
