@@ -132,6 +132,11 @@ struct DeviceGuard {
 
 void checksum_reset_reserved_cus();        // checksum.hip
 void inflate_pool_shutdown();              // inflate_many.hip: pooled worker resources
+// inflate_resolve.hip: the device stage for a batch of streams in one set of launches (layout: see there);
+// d_streams = array of {u64 v_start, const u8 *d_window, u64 window_len}
+int inflate_resolve_batch(const uint32_t *d_tokens, const uint8_t *d_literals, size_t nliterals, const uint64_t *d_segs,
+                          size_t nsegs, uint16_t *sym, const uint64_t *d_seg_dst, const uint64_t *d_seg_end,
+                          const void *d_streams, size_t nstreams, hipStream_t st);
 
 // checksum.hip: one streaming pass (+ finalize) over device-resident bytes.  d_dst != nullptr = fold_copy.  When a
 // d_seed_* pointer is given, that checksum's seed is read ON THE DEVICE from it at finalize time (the word an earlier

@@ -191,19 +191,38 @@ void inflate_window_kernel(const uint8_t *__restrict__ window, uint32_t window_l
     sym[(long long)k - kCtx] = k >= gap ? (uint16_t)window[k - gap] : (uint16_t)0;
 }
 
-// K3.  grid.x = segment
+// the same for a BATCH of streams laid out one behind the other in symbol space, each behind its own 32768-symbol
+// window gap (see resolve_batch below): blockIdx.y = stream
+struct BatchStream {
+    uint64_t       v_start;     // symbol index of the stream's first byte
+    const uint8_t *d_window;    // its window_len bytes of history (device) or null
+    uint64_t       window_len;
+};
+__global__ __launch_bounds__(256)
+void inflate_windows_kernel(const BatchStream *__restrict__ streams, uint16_t *__restrict__ sym) {
+    const BatchStream b = streams[blockIdx.y];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;            // 0 .. 32767
+    const uint32_t gap = (uint32_t)kCtx - (uint32_t)b.window_len;
+    sym[(long long)b.v_start - kCtx + k] = k >= gap ? (uint16_t)b.d_window[k - gap] : (uint16_t)0;
+}
+
+// K3.  grid.x = segment.  seg_dst / seg_end (batches only): where the segment's bytes go (the streams of a batch have
+// separate destinations) and where its real bytes end (a stream's last segment runs on through the next window gap).
 __global__ __launch_bounds__(1024)
 void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, const uint16_t *__restrict__ sym,
-                              uint8_t *__restrict__ out) {
+                              uint8_t *__restrict__ out, const uint64_t *__restrict__ seg_dst,
+                              const uint64_t *__restrict__ seg_end) {
     const size_t s = blockIdx.x;
     const long long o0 = (long long)segs[3 * s + 1], o1 = (long long)segs[3 * s + 4];
+    const long long stop = seg_end ? (long long)seg_end[s] : o1;
+    if (seg_dst) out = reinterpret_cast<uint8_t *>(seg_dst[s]) - o0;
     const long long tail = s + 1 < nsegs ? o1 - kCtx : o1;          // first symbol pass A/B rewrote
     const uint16_t *prev = sym + (o0 - kCtx);                       // tail of segment s-1
     const size_t gs = (s / kGroup) * kGroup;                        // base of this segment's group ...
     const uint16_t *base_own = sym + ((long long)segs[3 * gs + 1] - kCtx);
     const size_t gp = s ? ((s - 1) / kGroup) * kGroup : 0;          // ... and of the previous segment's
     const uint16_t *base_prev = sym + ((long long)segs[3 * gp + 1] - kCtx);
-    for (long long i = o0 + threadIdx.x; i < o1; i += blockDim.x) {
+    for (long long i = o0 + threadIdx.x; i < stop; i += blockDim.x) {
         uint16_t v = sym[i];
         if (v >= 256) {
             if (i >= tail) {
@@ -215,6 +234,38 @@ void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, c
         }
         __builtin_nontemporal_store((uint8_t)v, out + i);
     }
+}
+
+// Device stage for a batch of independent streams in ONE set of launches (inflate_many.hip).  The streams sit one
+// behind the other in symbol space, stream k at v_start_k = v_start_(k-1) + len_(k-1) + 32768: the 32768 symbols in
+// front of each are its window (the caller's history, or zeros), and the LAST segment of every stream is extended
+// through the gap that follows it, so that every segment but the batch's last still holds >= 32 KiB and the context
+// chain runs over the whole batch as over one stream -- a gap holds plain bytes only, so nothing crosses it.
+//   d_segs: (nsegs + 1) triples with batch-wide token / symbol / literal positions
+//   d_seg_dst / d_seg_end: per segment, destination address of its first byte and symbol index where its bytes end
+int inflate_resolve_batch(const uint32_t *d_tokens, const uint8_t *d_literals, size_t nliterals, const uint64_t *d_segs,
+                          size_t nsegs, uint16_t *sym, const uint64_t *d_seg_dst, const uint64_t *d_seg_end,
+                          const void *d_streams, size_t nstreams, hipStream_t st) {
+    if (!nsegs || !nstreams) return ZNG_ROCM_OK;
+    hipLaunchKernelGGL(inflate_windows_kernel, dim3((unsigned)(kCtx / 256), (unsigned)nstreams), dim3(256), 0, st,
+                       (const BatchStream *)d_streams, sym);
+    ZR_HIP(hipGetLastError());
+    ZR_LAUNCH_TRACED(inflate_segments_kernel, dim3((unsigned)((nsegs + 3) / 4)), dim3(256), st, d_tokens, d_literals,
+                     nliterals, d_segs, nsegs, sym);
+    ZR_HIP(hipGetLastError());
+    if (nsegs > 1) {
+        const unsigned ngroups = (unsigned)((nsegs - 1 + kGroup - 1) / kGroup);
+        hipLaunchKernelGGL(inflate_context_group_kernel, dim3(ngroups), dim3(1024), 0, st, d_segs, nsegs, sym, 1);
+        ZR_HIP(hipGetLastError());
+        if (ngroups > 1) {
+            hipLaunchKernelGGL(inflate_context_chain_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, sym);
+            ZR_HIP(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, sym,
+                       (uint8_t *)nullptr, d_seg_dst, d_seg_end);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
 }
 
 }  // namespace zr
@@ -246,7 +297,8 @@ static int resolve_impl(const uint32_t *d_tokens, const uint8_t *d_literals, siz
             ZR_HIP(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, sym, d_out);
+    hipLaunchKernelGGL(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), 0, st, d_segs, nsegs, sym, d_out,
+                       (const uint64_t *)nullptr, (const uint64_t *)nullptr);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }
