@@ -250,6 +250,24 @@ def main():
             "cpu_python_zlib_inflate_out_MBps_1thread": round(n / 1e6 / t_pyinf, 1),
             "cpu_python_zlib_deflate6_in_MBps_1thread": round(n / 1e6 / t_comp, 1)}
         del d_tok, d_lit, d_seg, d_sym, d_out, dst
+        # the same ONE stream with its host decode on T threads (parts cut at block boundaries found by search)
+        hs = inf.HostStream(comp)
+        dst = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        single = {}
+        for T in (4, 16, min(64, os.cpu_count() or 1)):
+            inf.inflate_raw_threads(hs, dst, nthreads=T)                    # warm: the pooled pinned arrays
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc_t, produced_t, _ = inf.inflate_raw_threads(hs, dst, nthreads=T)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            single["threads_%d" % T] = {"end_to_end_s": round(best, 4), "out_GBps": round(n / 1e9 / best, 2),
+                                        "in_GBps": round(len(comp) / 1e9 / best, 2),
+                                        "parts_joined": rocm.lib().zng_rocm_inflate_threads_last_parts(),
+                                        "bit_exact": bool(rc_t == 1 and produced_t == n and torch.equal(dst[:n], torch.from_numpy(plain).cuda()))}
+        report["cfg3"]["one_stream_decode_on_T_threads"] = single
+        del dst
         # many independent streams (the pigz shape): the same 256 MiB as 64 streams of 4 MiB, each compressed by the
         # device's own level-6 class (validated in cfg4), decoded on T host threads, resolved per stream on the device
         each = n // 64

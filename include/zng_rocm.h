@@ -298,6 +298,15 @@ void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
 int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
                                   size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
                                   uint8_t *d_out, uint64_t out_len, void *stream);
+/* ... and on `nthreads` host threads (<= 0: one per hardware thread): the compressed bytes are cut into parts, each
+ * thread finds a block boundary in its part (a valid dynamic block header or a sync-flush marker) and decodes from
+ * there; the parts are then chained from bit 0 and joined.  Same token stream semantics, status and messages as the
+ * one-thread decoder (irregular streams are simply handed to it); streams without findable boundaries (all blocks
+ * fixed-Huffman or stored) decode on one thread. */
+int  zng_rocm_inflate_tokens_decode_threads(const uint8_t *src, size_t src_len, uint32_t window_len, int nthreads,
+                                            zng_rocm_inflate_tokens *out);
+/* how many parts the calling thread's last multi-threaded decode was joined from (0 = the one-thread decoder did it) */
+int  zng_rocm_inflate_threads_last_parts(void);
 /* resolve with a prior window: `d_window` holds the window_len bytes that precede the stream (device);
  * d_symbols must then have room for 32768 + out_len uint16_t (the window's symbols are laid in front) */
 int  zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
@@ -336,6 +345,12 @@ typedef struct zng_rocm_inflate_job {
     const char    *msg;
 } zng_rocm_inflate_job;
 int  zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthreads);
+
+/* ONE raw stream with its host decode spread over `nthreads` threads (zng_rocm_inflate_tokens_decode_threads) and one
+ * device pass; same results and status as zng_rocm_inflate_raw_window, which it falls back to for streams that
+ * offer no block boundary to cut at or turn out irregular.  Synchronous. */
+int  zng_rocm_inflate_raw_threads(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                  uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, int nthreads);
 
 /* ---- compress2 / uncompress2 class front ends (compress.c:31-98, uncompr.c:25-76) ---------------------
  * `format`: 0 = raw deflate, 1 = zlib (RFC 1950), 2 = gzip (RFC 1952).  The trailer checksum (Adler-32 /

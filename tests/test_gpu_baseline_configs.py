@@ -49,6 +49,12 @@ def test_cfg3_inflate_256mib(mods, plain256):
     rc, produced = inf.inflate_raw(comp, dst)
     assert rc == 1 and produced == plain256.size
     assert torch.equal(dst[:produced], torch.from_numpy(plain256).cuda())
+    # the same stream with its host decode spread over the host's threads
+    dst.zero_()
+    rc, produced, used = inf.inflate_raw_threads(comp, dst, nthreads=0)
+    assert (rc, produced, used) == (1, plain256.size, len(comp))
+    assert zr.lib().zng_rocm_inflate_threads_last_parts() >= 2
+    assert torch.equal(dst[:produced], torch.from_numpy(plain256).cuda())
     # and the token route the one-shot uses, with its segment count (>= 32 KiB of output per segment)
     dec = inf.decode_tokens(comp)
     assert dec.status == 1 and dec.in_used == len(comp) and 8000 <= dec.nsegs <= 8192

@@ -202,3 +202,42 @@ def test_inflate_many_threads(inf):
                 assert dsts[i][:out_len].cpu().numpy().tobytes() == want, (nthreads, i)
             elif st == -3:
                 assert msg == omsg and dsts[i][:out_len].cpu().numpy().tobytes() == want
+
+
+def test_one_stream_on_many_host_threads(inf):
+    """zng_rocm_inflate_raw_threads: ONE stream, host decode cut into parts at block boundaries found by search and run
+    on several threads, one device pass over the joined token stream.  Bit-exact against the plaintext; irregular
+    streams take the one-thread path and report what it reports."""
+    torch = torch_mod()
+    zr = product()
+    plain = synth.silesia_like(48 << 20, seed=0x5EED0003, seg_bytes=4 << 20).tobytes()
+    want = torch.from_numpy(np.frombuffer(plain, dtype=np.uint8).copy()).cuda()
+    dst = torch.zeros(len(plain) + 64, dtype=torch.uint8, device="cuda")
+    for level in (6, 1):
+        comp = _raw_deflate(plain, level)
+        for T in (2, 8, 0):
+            dst.zero_()
+            rc, produced, used = inf.inflate_raw_threads(comp, dst, nthreads=T)
+            assert (rc, produced, used) == (1, len(plain), len(comp)), (level, T)
+            assert zr.lib().zng_rocm_inflate_threads_last_parts() >= 2
+            assert torch.equal(dst[:produced], want)
+    # continuing a window; a window that is too short (found when the parts are joined -> the reference's message)
+    dictionary = plain[:32768]
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=dictionary)
+    body = plain[10000:10000 + (20 << 20)]
+    comp = c.compress(body) + c.flush()
+    d_win = want[:32768].contiguous()
+    rc, produced, used = inf.inflate_raw_threads(comp, dst, window=d_win, nthreads=8)
+    assert (rc, produced) == (1, len(body)) and dst[:produced].cpu().numpy().tobytes() == body
+    rc, _, _ = inf.inflate_raw_threads(comp, dst, window=d_win[-50:].contiguous(), nthreads=8)
+    assert rc == -3 and b"invalid distance too far back" in zr.lib().zng_rocm_last_error()
+    # a damaged stream and a truncated one: same status and output as the one-thread call
+    comp = bytearray(_raw_deflate(plain[:16 << 20], 6))
+    comp[len(comp) // 2] ^= 0x04
+    ref = torch.zeros(len(plain) + 64, dtype=torch.uint8, device="cuda")
+    for bad in (bytes(comp), bytes(comp[:len(comp) // 3])):
+        rc1, n1 = inf.inflate_raw(bad, ref)
+        rc2, n2, _ = inf.inflate_raw_threads(bad, dst, nthreads=8)
+        assert (rc1, n1) == (rc2, n2) and torch.equal(ref[:n1], dst[:n2])
+    small = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    assert inf.inflate_raw_threads(_raw_deflate(plain[:8 << 20], 6), small, nthreads=8)[0] == -5

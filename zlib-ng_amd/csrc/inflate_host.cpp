@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "../../include/zng_rocm.h"
+#include "inflate_threads.h"
 
 namespace {
 
@@ -236,9 +237,18 @@ struct Bits {
 #define FAIL(m) do { t->status = Z_DATA_ERROR_; t->msg = (m); goto done; } while (0)
 #define STARVE() do { t->status = Z_BUF_ERROR_; t->msg = "input ended before the final block"; goto done; } while (0)
 
+}  // namespace
+
+// Control block of a PARTIAL decode (the parts of the multi-threaded single-stream inflate, inflate_threads.cpp):
+// start in the middle of the stream, at the bit where a block header begins (start_bit), and stop when a block ends
+// exactly on one of the given ascending bit positions (stops: where other threads' decodes start).  On return
+// end_bit = first bit behind the last block decoded, max_reach = max over all matches of (distance - bytes produced
+// before the match), hit_stop = 1 when it stopped on a stop position (status Z_OK: the stream goes on there).
+namespace {
+
 // caps: capacities (in elements: tokens, literal bytes, seg words) of the arrays `t` already owns; updated on return
 int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_rocm_inflate_tokens *t,
-                  ReallocFn re = plain_realloc, size_t *caps = nullptr) {
+                  ReallocFn re = plain_realloc, size_t *caps = nullptr, ZrDecodeCtl *ctl = nullptr) {
     Out o;
     o.t = t;
     o.re = re;
@@ -253,6 +263,15 @@ int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_r
     o.run = 0;
     o.oom = false;
     Bits b{src, src + src_len, 0, 0};
+    size_t stop_i = 0;
+    uint64_t max_reach = 0;
+    const size_t expect = ctl && ctl->size_hint ? ctl->size_hint : src_len;
+    if (ctl) {
+        ctl->hit_stop = 0;
+        b.next = src + (ctl->start_bit >> 3);
+        if (b.next > b.end) b.next = b.end;
+        while (stop_i < ctl->nstops && ctl->stops[stop_i] <= ctl->start_bit) ++stop_i;
+    }
     static thread_local Ent lentab[(1 << 10) + 1024], disttab[(1 << 9) + 512], cltab[(1 << 7) + 128];
     int lenroot = 0, distroot = 0, clroot = 0;
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -264,13 +283,26 @@ int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_r
     if (o.oom) goto oom;
     t->segs[0] = t->segs[1] = t->segs[2] = 0;
     t->nsegs = 1;
-    grow(o.re, (void **)&t->tokens, &o.tok_cap, src_len / 2 + 1024, 4, &o.oom);
-    grow(o.re, (void **)&t->literals, &o.lit_cap, src_len + 4096, 1, &o.oom);
+    grow(o.re, (void **)&t->tokens, &o.tok_cap, expect / 2 + 1024, 4, &o.oom);
+    grow(o.re, (void **)&t->literals, &o.lit_cap, expect + 4096, 1, &o.oom);
     if (o.oom) goto oom;
     t->status = Z_OK_;
     t->msg = "";
+    if (ctl && (ctl->start_bit & 7)) {
+        if (!b.need((unsigned)(ctl->start_bit & 7))) STARVE();
+        b.drop((unsigned)(ctl->start_bit & 7));
+    }
 
     while (!last) {
+        if (ctl && ctl->nstops) {
+            // a block has just ended (or none has begun): is this where another thread's decode starts?
+            const uint64_t pos = 8ull * (uint64_t)(b.next - src) - b.cnt;
+            while (stop_i < ctl->nstops && ctl->stops[stop_i] < pos) ++stop_i;
+            if (pos != ctl->start_bit && stop_i < ctl->nstops && ctl->stops[stop_i] == pos) {
+                ctl->hit_stop = 1;
+                goto done;                   // status stays Z_OK: the stream goes on
+            }
+        }
         if (!b.need(3)) STARVE();
         last = b.peek(1);
         b.drop(1);
@@ -440,7 +472,10 @@ int decode_stream(const uint8_t *src, size_t src_len, uint64_t window_len, zng_r
             b.drop(d.bits);
             unsigned dist = d.val + b.peek(xb);
             b.drop(xb);
-            if (dist > o.out_pos + window_len) FAIL("invalid distance too far back");
+            if (dist > o.out_pos) {
+                if (dist > o.out_pos + window_len) FAIL("invalid distance too far back");
+                if (dist - o.out_pos > max_reach) max_reach = dist - o.out_pos;
+            }
             flush_run(o);
             maybe_new_segment(o);
             push_token(o, 0x80000000u | ((len - 3) << 16) | (dist - 1));
@@ -463,6 +498,10 @@ done:
     }
     t->out_len = o.out_pos;
     t->in_used = (size_t)(b.next - src) - (b.cnt >> 3);
+    if (ctl) {
+        ctl->end_bit = 8ull * (uint64_t)(b.next - src) - b.cnt;
+        ctl->max_reach = max_reach;
+    }
     return t->status;
 oom:
     t->status = Z_MEM_ERROR_;
@@ -471,6 +510,186 @@ oom:
 }
 
 }  // namespace
+
+// ---- where does a deflate block start?  (multi-threaded single-stream inflate) ------------------------------------
+// A thread that is to decode the middle of a stream first has to find a block boundary.  Block headers carry no
+// marker, so every bit position of the thread's range is tried: it is a candidate when a DYNAMIC block header that
+// the decoder would accept starts there (RFC 1951 3.2.7 and the validity rules of inftrees.c:108-131 leave about one
+// random position in 10^6 standing), or when the empty stored block of a Z_SYNC_FLUSH / Z_FULL_FLUSH does (three zero
+// bits, zero padding, 00 00 ff ff: deflate.c:1064-1076 -- what pigz and this library's own encoders put between
+// their blocks).  Fixed-Huffman and non-empty stored blocks cannot be told from noise and are never candidates; a
+// stream made of nothing else simply decodes on one thread.  A candidate is only a guess: it counts once the decode
+// of the part before it ENDS exactly there.
+namespace {
+
+inline uint64_t bits_at(const uint8_t *src, size_t src_len, uint64_t bit) {        // 57+ bits starting at `bit`
+    const size_t byte = (size_t)(bit >> 3);
+    uint64_t w = 0;
+    if (byte + 8 <= src_len) memcpy(&w, src + byte, 8);
+    else if (byte < src_len) memcpy(&w, src + byte, src_len - byte);
+    return w >> (bit & 7);
+}
+
+bool plausible_dynamic_header(const uint8_t *src, size_t src_len, uint64_t bit) {
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint64_t w = bits_at(src, src_len, bit + 3);
+    const unsigned nlen = (unsigned)(w & 31) + 257, ndist = (unsigned)((w >> 5) & 31) + 1, ncode = (unsigned)((w >> 10) & 15) + 4;
+    if (nlen > 286 || ndist > 30) return false;
+    uint16_t cl[19] = {0};
+    uint64_t pos = bit + 17;
+    unsigned kraft = 0;                                   // a CODES set must be complete (inftrees.c:126-131)
+    for (unsigned i = 0; i < ncode; ++i, pos += 3) {
+        const unsigned l = (unsigned)(bits_at(src, src_len, pos) & 7);
+        cl[order[i]] = (uint16_t)l;
+        if (l) kraft += 128u >> l;
+    }
+    if (kraft != 128u) return false;
+    if ((pos >> 3) + 8 > src_len) return false;           // too close to the end to be worth a thread
+    Ent cltab[(1 << 7) + 128];
+    int clroot = 0;
+    if (build_table(T_CODES, cl, 19, 7, cltab, &clroot)) return false;
+    uint16_t lens[320];
+    unsigned have = 0;
+    while (have < nlen + ndist) {
+        const uint64_t v = bits_at(src, src_len, pos);
+        const Ent e = cltab[v & ((1u << clroot) - 1)];
+        if (e.kind & K_BAD) return false;
+        pos += e.bits;
+        const unsigned sym = e.val;
+        if (sym < 16) {
+            lens[have++] = (uint16_t)sym;
+            continue;
+        }
+        unsigned rep, val = 0;
+        const uint64_t x = v >> e.bits;
+        if (sym == 16) {
+            if (have == 0) return false;
+            val = lens[have - 1];
+            rep = 3 + (unsigned)(x & 3);
+            pos += 2;
+        } else if (sym == 17) {
+            rep = 3 + (unsigned)(x & 7);
+            pos += 3;
+        } else {
+            rep = 11 + (unsigned)(x & 127);
+            pos += 7;
+        }
+        if (have + rep > nlen + ndist) return false;
+        while (rep--) lens[have++] = (uint16_t)val;
+        if ((pos >> 3) + 8 > src_len) return false;
+    }
+    if (lens[256] == 0) return false;
+    static thread_local Ent lentab[(1 << 10) + 1024], disttab[(1 << 9) + 512];
+    int root = 0;
+    if (build_table(T_LENS, lens, (int)nlen, 10, lentab, &root)) return false;
+    if (build_table(T_DISTS, lens + nlen, (int)ndist, 9, disttab, &root)) return false;
+    return true;
+}
+
+}  // namespace
+
+namespace {
+
+// the first 13 bits of a block header: BFINAL, BTYPE, HLIT, HDIST -- set when they can belong to a dynamic block
+// (BTYPE 10, at most 286 literal/length and 30 distance codes: inflate.c:808-813)
+struct FinderTables {
+    uint8_t  hdr_ok[8192];
+    uint16_t kraft9[512];       // three 3-bit code lengths -> their share of the Kraft sum, in 1/128
+    FinderTables() {
+        for (unsigned v = 0; v < 8192; ++v)
+            hdr_ok[v] = ((v >> 1) & 3) == 2 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+        for (unsigned v = 0; v < 512; ++v) {
+            unsigned sum = 0;
+            for (int f = 0; f < 3; ++f) {
+                const unsigned l = (v >> (3 * f)) & 7;
+                if (l) sum += 128u >> l;
+            }
+            kraft9[v] = (uint16_t)sum;
+        }
+    }
+};
+const FinderTables &finder_tables() {
+    static const FinderTables t;
+    return t;
+}
+
+// is the code-length code of the dynamic header at `bit` complete?  (the cheap half of plausible_dynamic_header)
+inline bool cl_code_complete(const FinderTables &ft, const uint8_t *src, size_t src_len, uint64_t bit, uint64_t v) {
+    const unsigned ncode = (unsigned)((v >> 13) & 15) + 4;
+    uint64_t c = bits_at(src, src_len, bit + 17);                       // 57 bits: all 19 fields
+    if (ncode < 19) c &= (1ull << (3 * ncode)) - 1;
+    unsigned sum = 0;
+    for (int g = 0; g < 7; ++g) sum += ft.kraft9[(c >> (9 * g)) & 511];
+    return sum == 128u;
+}
+
+// a stored block whose header byte sits at byte `b` (BTYPE 00 in bits 1-2, LEN and NLEN behind it)?
+inline bool stored_at(const uint8_t *src, size_t src_len, uint64_t b, uint32_t *len) {
+    if (b + 5 > src_len || (src[b] & 6) != 0) return false;
+    const uint32_t ln = src[b + 1] | ((uint32_t)src[b + 2] << 8), nl = src[b + 3] | ((uint32_t)src[b + 4] << 8);
+    if ((ln ^ nl) != 0xffffu) return false;
+    *len = ln;
+    return true;
+}
+
+}  // namespace
+
+// first candidate block start in [from_bit, to_bit), or ~0.  Candidates:
+//   * a dynamic block header the decoder would accept, at any bit offset;
+//   * the sync-flush marker (empty stored block), at any bit offset;
+//   * a stored block whose header byte is on a byte boundary (it follows another stored block: incompressible
+//     stretches are nothing else) and behind whose payload another recognisable header follows.
+// The search gives up after kScanBytes: a part without a candidate is simply decoded by the thread in front of it.
+constexpr uint64_t kScanBytes = 192u << 10;
+
+uint64_t zr_inflate_find_block(const uint8_t *src, size_t src_len, uint64_t from_bit, uint64_t to_bit) {
+    const FinderTables &ft = finder_tables();
+    const uint64_t limit = 8ull * src_len;
+    if (to_bit > limit) to_bit = limit;
+    if (to_bit > from_bit + 8 * kScanBytes) to_bit = from_bit + 8 * kScanBytes;
+    for (uint64_t bit = from_bit; bit < to_bit; ++bit) {
+        const uint64_t v = bits_at(src, src_len, bit);
+        if (ft.hdr_ok[v & 8191]) {
+            if (cl_code_complete(ft, src, src_len, bit, v) && plausible_dynamic_header(src, src_len, bit)) return bit;
+            continue;
+        }
+        if ((v & 6) != 0) continue;                                  // BTYPE 00 from here on
+        if ((v & 1) == 0) {
+            // the sync marker: header 000, zero padding up to the byte boundary, LEN = 0, NLEN = 0xffff
+            const unsigned pad = (unsigned)((8 - ((bit + 3) & 7)) & 7);
+            if (((v >> 3) & ((1u << pad) - 1)) == 0) {
+                const uint64_t q = (bit + 3 + pad) >> 3;
+                if (q + 4 <= src_len && src[q] == 0 && src[q + 1] == 0 && src[q + 2] == 0xff && src[q + 3] == 0xff) return bit;
+            }
+        }
+        if ((bit & 7) == 0) {
+            uint32_t len = 0, len2 = 0;
+            const uint64_t b = bit >> 3;
+            if (stored_at(src, src_len, b, &len) && len) {
+                const uint64_t nb = b + 5 + len;                     // where the next block header must be
+                if (nb + 8 <= src_len) {
+                    const uint64_t nv = bits_at(src, src_len, 8 * nb);
+                    if (stored_at(src, src_len, nb, &len2) ||
+                        (ft.hdr_ok[nv & 8191] && cl_code_complete(ft, src, src_len, 8 * nb, nv)))
+                        return bit;
+                }
+            }
+        }
+    }
+    return ~0ull;
+}
+
+// decode from ctl->start_bit until a block ends on one of ctl->stops or the stream ends; arrays are carried over
+int zr_inflate_decode_part(const uint8_t *src, size_t src_len, zng_rocm_inflate_tokens *t, size_t caps[3],
+                           void *(*re)(void *, size_t, size_t), ZrDecodeCtl *ctl) {
+    if (!re) re = plain_realloc;
+    t->ntokens = t->nliterals = t->nsegs = 0;
+    t->out_len = 0;
+    t->in_used = 0;
+    t->status = 0;
+    t->msg = "";
+    return decode_stream(src, src_len, 32768, t, re, caps, ctl);       // history is checked when the parts are joined
+}
 
 // internal (inflate_many.hip): decode into arrays the caller keeps across streams -- `t`'s pointers and `caps` are
 // carried over, its counters are reset; arrays grow through `re`

@@ -17,6 +17,7 @@
 // its own HIP stream" topped out at 4.9 GB/s of output however many threads decoded (7.9 GB/s with
 // GPU_MAX_HW_QUEUES=16; the decode alone reaches 13.7 GB/s on 16 threads).  A batch fills the machine instead.
 #include "context.h"
+#include "inflate_threads.h"
 
 #include <string.h>
 
@@ -27,6 +28,10 @@
 #include <thread>
 #include <vector>
 
+extern "C" int zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
+                                                   size_t nliterals, const uint64_t *d_segs, size_t nsegs,
+                                                   uint16_t *d_symbols, uint8_t *d_out, uint64_t out_len,
+                                                   const uint8_t *d_window, uint32_t window_len, void *stream);
 int zr_inflate_decode_reuse(const uint8_t *src, size_t src_len, uint32_t window_len, zng_rocm_inflate_tokens *t,
                             size_t caps[3], void *(*re)(void *, size_t, size_t));
 
@@ -37,7 +42,7 @@ namespace zr {
 // stream pays page faults for fresh arrays.  Growth = new pinned block, copy, free.
 static void *pinned_realloc(void *old, size_t old_bytes, size_t new_bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, new_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, new_bytes, hipHostMallocPortable) != hipSuccess) return nullptr;      // any thread, any device
     if (old) {
         memcpy(p, old, old_bytes < new_bytes ? old_bytes : new_bytes);
         (void)hipHostFree(old);
@@ -90,6 +95,7 @@ struct Engine {
     hipStream_t st = nullptr;
     BatchSlot   slot[2];
     std::vector<TokenSet *> all_sets;
+    std::vector<ZrPart> parts;                // the parts of the multi-threaded single-stream decode (pinned arrays)
 };
 
 static std::mutex g_pool_mu;
@@ -109,6 +115,11 @@ static void destroy_engine(Engine *e, bool device_alive) {
             if (ts->tk.tokens) (void)hipHostFree(ts->tk.tokens);
             if (ts->tk.literals) (void)hipHostFree(ts->tk.literals);
             if (ts->tk.segs) (void)hipHostFree(ts->tk.segs);
+        }
+        for (ZrPart &p : e->parts) {
+            if (p.tk.tokens) (void)hipHostFree(p.tk.tokens);
+            if (p.tk.literals) (void)hipHostFree(p.tk.literals);
+            if (p.tk.segs) (void)hipHostFree(p.tk.segs);
         }
         if (e->st) {
             (void)zng_rocm_stream_release(e->st);
@@ -375,6 +386,99 @@ int zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthreads
     if (hipStreamSynchronize(e->st) != hipSuccess && rc == ZNG_ROCM_OK) rc = ZNG_ROCM_EHIP;
     release_engine(e);
     return rc;
+}
+
+
+// One raw stream, decoded on `nthreads` host threads (inflate_threads.cpp), resolved on the device in one pass.
+int zng_rocm_inflate_raw_threads(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                 uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, int nthreads) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if ((!src && src_len) || window_len > 32768u || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
+    DeviceGuard dev;
+    unsigned t = nthreads > 0 ? (unsigned)nthreads : std::thread::hardware_concurrency();
+    if (t == 0) t = 1;
+    Engine *e = acquire_engine();
+    if (!e) return ZNG_ROCM_EHIP;
+    const size_t max_parts = 8u * (size_t)t;
+    while (e->parts.size() < max_parts) {
+        ZrPart p;
+        memset(&p, 0, sizeof(p));
+        e->parts.push_back(p);
+    }
+    std::vector<size_t> chain;
+    ZrThreadsResult res;
+    memset(&res, 0, sizeof(res));
+    const int drc = zr_inflate_decode_threads(src, src_len, window_len, t, pinned_realloc, e->parts.data(), max_parts,
+                                              &chain, &res);
+    zr_inflate_note_parts(drc == ZR_THREADS_OK ? (int)chain.size() : 0);
+    if (drc != ZR_THREADS_OK) {
+        release_engine(e);
+        if (drc == -4) return ZNG_ROCM_ENOMEM;
+        // nothing to cut it at, or something irregular on the way: the one-thread path reports exactly what happened
+        return zng_rocm_inflate_raw_window(src, src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, nullptr);
+    }
+    if (out_len) *out_len = res.out_len;
+    if (in_used) *in_used = res.in_used;
+    if (res.out_len > dst_cap) {
+        set_error("inflate output (%llu bytes) exceeds dst_cap", (unsigned long long)res.out_len);
+        release_engine(e);
+        return -5;
+    }
+    int rc = ZNG_ROCM_OK;
+    if (res.out_len) {
+        // join the parts on the device: tokens and literals go up part by part (DMA from the parts' pinned arrays);
+        // a part's first segment is merged into the last segment of the part before it (that one may hold less than
+        // 32 KiB; every segment but the stream's last must hold more)
+        size_t ntok = 0, nlit = 0, nseg = 0;
+        for (size_t c = 0; c < chain.size(); ++c) {
+            const zng_rocm_inflate_tokens &tk = e->parts[chain[c]].tk;
+            ntok += tk.ntokens;
+            nlit += tk.nliterals;
+            nseg += tk.nsegs - (c ? 1 : 0);
+        }
+        BatchSlot &slot = e->slot[0];
+        auto go = [&]() -> int {
+            if (int r = slot.h_meta.reserve((nseg + 1) * 24)) return r;
+            if (int r = slot.d_meta.reserve((nseg + 1) * 24)) return r;
+            if (int r = slot.d_tokens.reserve(ntok * 4 + 256)) return r;
+            if (int r = slot.d_literals.reserve(nlit + 256)) return r;
+            if (int r = slot.d_sym.reserve(((size_t)res.out_len + 32768u) * 2)) return r;
+            uint64_t *segs = (uint64_t *)slot.h_meta.p;
+            uint32_t *d_tokens = (uint32_t *)slot.d_tokens.p;
+            uint8_t *d_literals = (uint8_t *)slot.d_literals.p;
+            uint64_t tok0 = 0, lit0 = 0, o0 = 0;
+            size_t s0 = 0;
+            for (size_t c = 0; c < chain.size(); ++c) {
+                const zng_rocm_inflate_tokens &tk = e->parts[chain[c]].tk;
+                if (tk.ntokens) ZR_HIP(hipMemcpyAsync(d_tokens + tok0, tk.tokens, tk.ntokens * 4, hipMemcpyHostToDevice, e->st));
+                if (tk.nliterals) ZR_HIP(hipMemcpyAsync(d_literals + lit0, tk.literals, tk.nliterals, hipMemcpyHostToDevice, e->st));
+                for (size_t sg = c ? 1 : 0; sg < tk.nsegs; ++sg, ++s0) {
+                    segs[3 * s0] = tk.segs[3 * sg] + tok0;
+                    segs[3 * s0 + 1] = tk.segs[3 * sg + 1] + o0;
+                    segs[3 * s0 + 2] = tk.segs[3 * sg + 2] + lit0;
+                }
+                tok0 += tk.ntokens;
+                lit0 += tk.nliterals;
+                o0 += tk.out_len;
+            }
+            segs[3 * s0] = tok0;
+            segs[3 * s0 + 1] = o0;
+            segs[3 * s0 + 2] = lit0;
+            ZR_HIP(hipMemcpyAsync(slot.d_meta.p, slot.h_meta.p, (nseg + 1) * 24, hipMemcpyHostToDevice, e->st));
+            if (int r = zng_rocm_inflate_resolve_window_dev(d_tokens, ntok, d_literals, nlit, (const uint64_t *)slot.d_meta.p, nseg,
+                                                            (uint16_t *)slot.d_sym.p, d_dst, res.out_len, d_window, window_len,
+                                                            e->st))
+                return r;
+            return ZNG_ROCM_OK;
+        };
+        rc = go();
+        if (hipStreamSynchronize(e->st) != hipSuccess && rc == ZNG_ROCM_OK) rc = ZNG_ROCM_EHIP;
+    }
+    release_engine(e);
+    return rc != ZNG_ROCM_OK ? rc : res.status;
 }
 
 }  // extern "C"

@@ -22,13 +22,17 @@ class InflateTokens(C.Structure):
 class DecodedStream:
     """numpy views of one decoded stream (copies; the C buffers are freed immediately)"""
 
-    def __init__(self, src, window_len=0):
+    def __init__(self, src, window_len=0, nthreads=1):
         import numpy as np
         lib = rocm.lib()
         raw = bytes(src)
         buf = C.create_string_buffer(raw, max(len(raw), 1))
         tk = InflateTokens()
-        self.status = lib.zng_rocm_inflate_tokens_decode_window(C.addressof(buf), len(raw), window_len, C.byref(tk))
+        if nthreads == 1:
+            self.status = lib.zng_rocm_inflate_tokens_decode_window(C.addressof(buf), len(raw), window_len, C.byref(tk))
+        else:
+            self.status = lib.zng_rocm_inflate_tokens_decode_threads(C.addressof(buf), len(raw), window_len, nthreads,
+                                                                     C.byref(tk))
         self.msg = (tk.msg or b"").decode()
         self.out_len = tk.out_len
         self.in_used = tk.in_used
@@ -43,8 +47,9 @@ class DecodedStream:
         lib.zng_rocm_inflate_tokens_free(C.byref(tk))
 
 
-def decode_tokens(src, window_len=0):
-    return DecodedStream(src, window_len)
+def decode_tokens(src, window_len=0, nthreads=1):
+    """nthreads != 1: the multi-threaded decode of ONE stream (0 = one thread per hardware thread)"""
+    return DecodedStream(src, window_len, nthreads)
 
 
 def resolve_dev(dec, stream=None):
@@ -130,3 +135,24 @@ def inflate_many(streams, dsts, windows=None, nthreads=0):
     """streams: list of bytes-like raw deflate streams (host); dsts: list of uint8 CUDA tensors; windows: optional list
     of uint8 CUDA tensors (or None) holding each stream's history.  Returns [(status, out_len, in_used, msg), ...]."""
     return InflateBatch(streams, dsts, windows).run(nthreads)
+
+
+class HostStream:
+    """a host copy of one compressed stream, made once (keeps the timing of repeated calls free of Python copies)"""
+
+    def __init__(self, src):
+        raw = bytes(src)
+        self.n = len(raw)
+        self.buf = C.create_string_buffer(raw, max(len(raw), 1))
+
+
+def inflate_raw_threads(src, dst, window=None, nthreads=0):
+    """one raw stream, host decode on `nthreads` threads (0 = all hardware threads), device resolve; `src` bytes-like or
+    a HostStream.  Returns (zlib status, bytes produced, input bytes used)"""
+    rocm._need_init()
+    hs = src if isinstance(src, HostStream) else HostStream(src)
+    produced, used = C.c_uint64(0), C.c_size_t(0)
+    wl = 0 if window is None else window.numel()
+    rc = rocm.lib().zng_rocm_inflate_raw_threads(C.addressof(hs.buf), hs.n, None if not wl else rocm._dev_ptr(window), wl,
+                                                 rocm._dev_ptr(dst), dst.numel(), C.byref(produced), C.byref(used), nthreads)
+    return rc, produced.value, used.value

@@ -89,6 +89,10 @@ _PROTOS = {
                                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zng_rocm_inflate_raw_window": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_void_p]),
+    "zng_rocm_inflate_tokens_decode_threads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]),
+    "zng_rocm_inflate_threads_last_parts": (C.c_int, []),
+    "zng_rocm_inflate_raw_threads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_int]),
     "zng_rocm_inflate_many": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     "zng_rocm_inflate_tokens_free": (None, [C.c_void_p]),
     "zng_rocm_inflate_resolve_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
