@@ -10,6 +10,8 @@ RCCL) followed by the ordered on-device combine.
 The same line carries a `streams` object at every N (BASELINE.json configs[4], the north_star's multi-stream
 curve): 4096 independent 1 MiB streams, level-1 class, sharded over the N ranks (strong scaling), the {clen,
 adler32, ulen} table all-gathered over RCCL; `streams.value` at N = 1, 2, 4, 8 is the 1 -> 8 GPU scaling curve.
+And the two single-stream members of the metric, `deflate_lvl6` (configs[3]) and `inflate` (configs[2]): one 256 MiB
+stream per GPU (a single stream does not shard: replicas at N > 1).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
@@ -48,10 +50,18 @@ REFERENCE_CONTAINER = {
 
 
 def host_threads():
+    """host cores this process may really use: its CPU affinity, capped by the control group's CPU quota"""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(host_view, zr, reps=3):
@@ -275,6 +285,76 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     del batch, src
     torch.cuda.empty_cache()
     return out
+
+
+def run_single_stream_legs(args, zr, torch, dist, dev, world, rank):
+    """The two single-stream members of the metric (BASELINE.json configs[2] and [3]): deflate level 6 of one 256 MiB
+    stream and raw inflate of it.  A single deflate / inflate stream does not shard over GPUs (32 KiB of history):
+    at N > 1 every rank runs its own replica ("replicas only") and the values are sums.
+    deflate: plaintext resident in HBM -> raw stream in HBM (zng_rocm_deflate_dev, includes its host synchronisation).
+    inflate: host stream -> plaintext in HBM, host decode on the threads this rank may use (zng_rocm_inflate_raw_threads),
+    and the same on one thread."""
+    import zlib
+
+    import synth
+    dfl = importlib.import_module("zlib-ng_amd.deflate")
+    inf = importlib.import_module("zlib-ng_amd.inflate")
+    n = 256 << 20
+    plain = synth.silesia_like(n, seed=0x5EED0003)
+    src = torch.from_numpy(plain).to(dev)
+    dst, clen = dfl.deflate_dev(src, level=6)                     # warm-up: allocates the per-stream scratch
+    torch.cuda.synchronize()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, reps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return dt.item()
+
+    t_def = timed(lambda: dfl.deflate_dev(src, level=6), 3)
+    comp = dst[:clen].cpu().numpy().tobytes()
+    d = zlib.decompressobj(-15)                                  # validity: an independent inflater restores the first 8 MiB
+    assert d.decompress(comp[:4 << 20], 8 << 20) == plain[:8 << 20].tobytes()
+    hs = inf.HostStream(comp)
+    out = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    T = max(1, host_threads() // world)
+    inf.inflate_raw_threads(hs, out, nthreads=T)                 # warm-up: the pooled pinned arrays
+    res = {}
+
+    def run_threads():
+        res["rc"] = inf.inflate_raw_threads(hs, out, nthreads=T)
+    t_inf = timed(run_threads, 3)
+    assert res["rc"][:2] == (1, n) and torch.equal(out[:n], src), "inflate output differs from the plaintext"
+    parts = zr.lib().zng_rocm_inflate_threads_last_parts()
+    t_inf1 = timed(lambda: inf.inflate_raw_threads(hs, out, nthreads=1), 1)
+    del src, dst, out
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    gb = n / 1e9
+    return {
+        "deflate_lvl6": {"workload": "configs[3]: deflate level-6 class of one 256 MiB Silesia-like stream per GPU, device resident",
+                         "value": round(world * gb / t_def, 2), "unit": "GB/s of input", "ms_per_stream": round(t_def * 1e3, 2),
+                         "ratio": round(n / clen, 3), "scaling": "replicas only" if world > 1 else "single",
+                         "reference_container_GBps": REFERENCE_CONTAINER["deflate_level6_GBps"]},
+        "inflate": {"workload": "configs[2]: raw inflate of that level-6 stream (host, %.1f MiB) into HBM, bit-exact vs the plaintext; "
+                                "host decode on %d threads cut at found block boundaries, device resolve" % (clen / 2**20, T),
+                    "value": round(world * gb / t_inf, 2), "unit": "GB/s of output", "ms_per_stream": round(t_inf * 1e3, 2),
+                    "in_GBps": round(world * clen / 1e9 / t_inf, 2), "host_threads": T, "parts_joined": parts,
+                    "one_host_thread_GBps": round(gb / t_inf1, 2),
+                    "scaling": "replicas only" if world > 1 else "single",
+                    "reference_container_GBps": REFERENCE_CONTAINER["inflate_out_GBps"]},
+    }
 
 
 def emit(line):
@@ -563,6 +643,9 @@ def main():
         s = run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, stream_steps, stream_warm)
         if rank == 0:
             line["streams"] = s
+        legs = run_single_stream_legs(args, zr, torch, dist, dev, world, rank)
+        if rank == 0:
+            line.update(legs)
     if rank == 0:
         emit(line)
 

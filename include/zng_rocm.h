@@ -298,7 +298,7 @@ void zng_rocm_inflate_tokens_free(zng_rocm_inflate_tokens *t);
 int  zng_rocm_inflate_resolve_dev(const uint32_t *d_tokens, size_t ntokens, const uint8_t *d_literals,
                                   size_t nliterals, const uint64_t *d_segs, size_t nsegs, uint16_t *d_symbols,
                                   uint8_t *d_out, uint64_t out_len, void *stream);
-/* ... and on `nthreads` host threads (<= 0: one per hardware thread): the compressed bytes are cut into parts, each
+/* ... and on `nthreads` host threads (<= 0: one per hardware thread, capped by the control group's CPU quota): the compressed bytes are cut into parts, each
  * thread finds a block boundary in its part (a valid dynamic block header or a sync-flush marker) and decodes from
  * there; the parts are then chained from bit 0 and joined.  Same token stream semantics, status and messages as the
  * one-thread decoder (irregular streams are simply handed to it); streams without findable boundaries (all blocks
@@ -327,7 +327,7 @@ int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst,
 int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                  uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
-/* Many independent raw streams at once: `nthreads` host threads (<= 0: one per hardware thread) take the jobs in
+/* Many independent raw streams at once: `nthreads` host threads (<= 0: as many as the host gives us) take the jobs in
  * order, each decoding on the host and resolving on the device on its own HIP stream, so that the sequential decode
  * -- where an inflate spends its time -- runs on all the cores the caller allows while the device work of one stream
  * overlaps the decode of the next (the pigz shape: test/pigz/CMakeLists.txt).  Per job: `src` host, `d_dst` device

@@ -12,6 +12,9 @@
 // One-shot contract: the whole raw stream is in `src`; "invalid distance too far back" = distance
 // larger than the bytes produced so far plus the `window_len` bytes of history the caller says precede the
 // stream (inffast_tpl.h:198-226; whave after inflateSetDictionary, inflate.c:1214-1261).
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE                  // memmem
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -636,7 +639,9 @@ inline bool stored_at(const uint8_t *src, size_t src_len, uint64_t b, uint32_t *
 
 // first candidate block start in [from_bit, to_bit), or ~0.  Candidates:
 //   * a dynamic block header the decoder would accept, at any bit offset;
-//   * the sync-flush marker (empty stored block), at any bit offset;
+//   * the block BEHIND a sync-flush marker (empty stored block: LEN = 0, NLEN = 0xffff -- the bytes 00 00 ff ff, on a
+//     byte boundary whatever came before): found by a plain byte search over the whole range first, at memory speed --
+//     what pigz, Z_SYNC_FLUSH / Z_FULL_FLUSH users and this library's own encoders put between their blocks;
 //   * a stored block whose header byte is on a byte boundary (it follows another stored block: incompressible
 //     stretches are nothing else) and behind whose payload another recognisable header follows.
 // The search gives up after kScanBytes: a part without a candidate is simply decoded by the thread in front of it.
@@ -646,6 +651,18 @@ uint64_t zr_inflate_find_block(const uint8_t *src, size_t src_len, uint64_t from
     const FinderTables &ft = finder_tables();
     const uint64_t limit = 8ull * src_len;
     if (to_bit > limit) to_bit = limit;
+    {
+        // markers first: the block that follows one starts on the byte boundary behind it
+        static const uint8_t marker[4] = {0x00, 0x00, 0xff, 0xff};
+        const size_t lo = (size_t)((from_bit + 7) >> 3), hi = (size_t)(to_bit >> 3);
+        if (hi > lo + 4) {
+            const void *hit = memmem(src + lo, hi - lo, marker, 4);
+            if (hit) {
+                const size_t q = (size_t)((const uint8_t *)hit - src) + 4;
+                if (q + 2 <= src_len) return 8ull * q;
+            }
+        }
+    }
     if (to_bit > from_bit + 8 * kScanBytes) to_bit = from_bit + 8 * kScanBytes;
     for (uint64_t bit = from_bit; bit < to_bit; ++bit) {
         const uint64_t v = bits_at(src, src_len, bit);

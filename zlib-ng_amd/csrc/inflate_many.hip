@@ -301,8 +301,7 @@ int zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthreads
         }
     }
     DeviceGuard dev;
-    unsigned t = nthreads > 0 ? (unsigned)nthreads : std::thread::hardware_concurrency();
-    if (t == 0) t = 1;
+    unsigned t = nthreads > 0 ? (unsigned)nthreads : zr_default_threads();
     if (t > njobs) t = (unsigned)njobs;
     Engine *e = acquire_engine();
     if (!e) return ZNG_ROCM_EHIP;
@@ -398,8 +397,7 @@ int zng_rocm_inflate_raw_threads(const uint8_t *src, size_t src_len, const uint8
     }
     if ((!src && src_len) || window_len > 32768u || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
     DeviceGuard dev;
-    unsigned t = nthreads > 0 ? (unsigned)nthreads : std::thread::hardware_concurrency();
-    if (t == 0) t = 1;
+    const unsigned t = nthreads > 0 ? (unsigned)nthreads : zr_default_threads();
     Engine *e = acquire_engine();
     if (!e) return ZNG_ROCM_EHIP;
     const size_t max_parts = 8u * (size_t)t;

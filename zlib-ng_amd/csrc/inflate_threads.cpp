@@ -16,6 +16,7 @@
 // The scheme is the one pugz / rapidgzip use for gzip files; streams whose blocks are all fixed-Huffman or stored
 // offer no candidates and decode on one thread.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -118,6 +119,26 @@ int zr_inflate_decode_threads(const uint8_t *src, size_t src_len, uint32_t windo
     }
 }
 
+// threads for "as many as the host gives us": the hardware threads, capped by the CPU quota of the control group the
+// process runs in (a container with 16 CPUs' worth of quota on a 256-thread host gains nothing from 256 threads)
+unsigned zr_default_threads() {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = "";
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && strcmp(quota, "max") != 0) {
+            const long q = atol(quota);
+            if (q > 0) {
+                const unsigned cap = (unsigned)((q + period - 1) / period);
+                if (cap && cap < t) t = cap;
+            }
+        }
+        fclose(f);
+    }
+    return t;
+}
+
 static thread_local int t_last_parts = 0;     // parts on the chain of this thread's last multi-threaded decode (0: one thread did it)
 void zr_inflate_note_parts(int n) { t_last_parts = n; }
 
@@ -128,8 +149,7 @@ int zng_rocm_inflate_threads_last_parts(void) { return t_last_parts; }
 int zng_rocm_inflate_tokens_decode_threads(const uint8_t *src, size_t src_len, uint32_t window_len, int nthreads,
                                            zng_rocm_inflate_tokens *out) {
     if (!out || (!src && src_len) || window_len > 32768u) return ZNG_ROCM_EINVAL;
-    unsigned t = nthreads > 0 ? (unsigned)nthreads : std::thread::hardware_concurrency();
-    if (t == 0) t = 1;
+    const unsigned t = nthreads > 0 ? (unsigned)nthreads : zr_default_threads();
     const size_t max_parts = 8u * (size_t)t;
     std::vector<ZrPart> parts(max_parts);
     for (ZrPart &p : parts) memset(&p, 0, sizeof(p));

@@ -43,3 +43,4 @@ int zr_inflate_decode_threads(const uint8_t *src, size_t src_len, uint32_t windo
                               void *(*re)(void *, size_t, size_t), ZrPart *parts, size_t max_parts,
                               std::vector<size_t> *chain, ZrThreadsResult *res);
 void zr_inflate_note_parts(int n);        // for zng_rocm_inflate_threads_last_parts()
+unsigned zr_default_threads();            // hardware threads, capped by the control group's CPU quota
