@@ -21,6 +21,46 @@ def replay(t):
     return bytes(out)
 rnd=random.Random(int(sys.argv[2]) if len(sys.argv)>2 else 1)
 n_ok=n_err=0
+if len(sys.argv)>4 and sys.argv[4]=="threads":
+    # larger streams through the multi-threaded decode of ONE stream (block search, partial decodes, chain, join):
+    # must agree with the one-thread decoder on status, bytes produced, input consumed -- and with CPython on the bytes
+    lib.zng_rocm_inflate_tokens_decode_threads.argtypes=[C.c_char_p,C.c_size_t,C.c_uint32,C.c_int,C.POINTER(Tok)]
+    nrng=np.random.default_rng(rnd.randrange(1<<30))
+    words=[bytes(nrng.integers(97,123,size=int(k),dtype=np.uint8))+b" " for k in nrng.integers(1,12,size=3000)]
+    for it in range(int(sys.argv[3])):
+        pieces=[]
+        for _ in range(rnd.randrange(2,6)):
+            kind=rnd.randrange(3)
+            if kind==0: pieces.append(b"".join(words[i] for i in (nrng.zipf(1.3,size=200000)-1)%len(words)))
+            elif kind==1: pieces.append(bytes(nrng.integers(0,256,size=rnd.randrange(200000,900000),dtype=np.uint8)))
+            else: pieces.append(bytes(nrng.integers(0,4,size=rnd.randrange(300000,2000000),dtype=np.uint8)))
+        data=b"".join(pieces)
+        c=zlib.compressobj(rnd.choice([1,6]),zlib.DEFLATED,-15)
+        parts=[]
+        for lo in range(0,len(data),1<<18):
+            parts.append(c.compress(data[lo:lo+(1<<18)]))
+            if rnd.randrange(4)==0: parts.append(c.flush(rnd.choice([zlib.Z_SYNC_FLUSH,zlib.Z_FULL_FLUSH])))
+        comp=bytearray(b"".join(parts)+c.flush())
+        mode=rnd.randrange(3)
+        if mode==1:
+            for _ in range(rnd.randrange(1,4)): comp[rnd.randrange(len(comp))]^=1<<rnd.randrange(8)
+        elif mode==2: comp=comp[:rnd.randrange(len(comp)//2,len(comp))]
+        comp=bytes(comp)
+        a=Tok(); sa=lib.zng_rocm_inflate_tokens_decode(comp,len(comp),C.byref(a))
+        b=Tok(); sb=lib.zng_rocm_inflate_tokens_decode_threads(comp,len(comp),0,rnd.choice([2,3,4,7]),C.byref(b))
+        assert (sa,a.out_len,a.in_used)==(sb,b.out_len,b.in_used),(it,mode,sa,sb)
+        if sb==1:
+            d=zlib.decompressobj(-15); ref=d.decompress(comp)
+            toks=np.ctypeslib.as_array(C.cast(b.tokens,C.POINTER(C.c_uint32)),(b.ntokens,))
+            # replay with numpy where it can: literals vectorised, matches in Python
+            assert d.eof and b.out_len==len(ref)
+            got=replay(b) if b.ntokens<400000 else None
+            assert got is None or got==ref,(it,mode)
+            n_ok+=1
+        else: n_err+=1
+        lib.zng_rocm_inflate_tokens_free(C.byref(a)); lib.zng_rocm_inflate_tokens_free(C.byref(b))
+    print("threads: ok",n_ok,"rejected",n_err)
+    sys.exit(0)
 for it in range(int(sys.argv[3]) if len(sys.argv)>3 else 400):
     kind=rnd.randrange(4)
     if kind==0: data=bytes(rnd.randrange(256) for _ in range(rnd.randrange(0,3000)))

@@ -24,6 +24,7 @@
 
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 namespace zr {
 
@@ -234,6 +235,270 @@ void deflate_quick_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__res
     }
 }
 
+// ---- the same coder with ONE wavefront per stream ------------------------------------------------------------------
+// For batches with enough streams to fill the machine by themselves (>= 8 per CU).  A stream is walked 64 positions at a
+// time by a single wave: no workgroup barrier exists in this kernel (the 256-lane form above has six per 256
+// positions), the greedy parse simply carries its "first byte not yet produced" from step to step in a scalar
+// register -- no speculation, no stitching -- and the one long-latency operation of a step, the gather of the
+// candidates' bytes, is issued a whole step ahead: while step k is parsed and coded, the hash insertions and the
+// candidate loads of step k+1 are already under way.  LDS per stream is the same (16 KiB head + 2 KiB bit ring), so a
+// CU holds eight such waves.
+struct WaveShared {
+    uint32_t head[1 << kQuickHashBits];
+    uint32_t ring[kRingWords];
+};
+
+__device__ __forceinline__ u32x4_unaligned shfl16(const u32x4_unaligned &v, int src) {
+    u32x4_unaligned r = {(uint32_t)__shfl((int)v.x, src, 64), (uint32_t)__shfl((int)v.y, src, 64),
+                         (uint32_t)__shfl((int)v.z, src, 64), (uint32_t)__shfl((int)v.w, src, 64)};
+    return r;
+}
+
+__global__ __launch_bounds__(64)
+void deflate_quick_wave_kernel(const StreamJobDev *__restrict__ jobs, uint32_t *__restrict__ results) {
+    __shared__ WaveShared sh;
+
+    const StreamJobDev job = jobs[blockIdx.x];
+    const uint8_t *in = job.in;
+    const uint32_t n = job.n, start = job.start;
+    const bool final_block = (job.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
+    uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
+    const int lane = threadIdx.x;
+
+    for (int i = lane; i < (1 << kQuickHashBits) / 4; i += 64) reinterpret_cast<uint4 *>(sh.head)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < (int)kRingWords; i += 64) sh.ring[i] = i == 0 ? (final_block ? 3u : 2u) : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    // one step's hash insertion: lanes of one LDS exchange are served in lane order (tools/micro/lds_xchg_order.hip), so
+    // every lane gets what quick_insert_string (insert_string_tpl.h:58-75) would have returned
+    auto insert = [&](uint32_t W, uint32_t first4) -> uint32_t {
+        const uint32_t p = W + (uint32_t)lane;
+        uint32_t old = 0;
+        if (p + kLzMinMatch <= n && p + kLzMinMatch > p) old = atomicExch(&sh.head[lz_hash<kQuickHashBits>(first4)], p + 1u);
+        return old;
+    };
+    auto load16 = [&](uint32_t p, bool inside) -> u32x4_unaligned {
+        return inside ? load_u128(in + p) : load_16_guarded(in, p, n);
+    };
+    const u32x4_unaligned zero16 = {0u, 0u, 0u, 0u};
+
+    // dictionary priming: whole steps below `start` only enter their positions into the hash
+    uint32_t W0 = 0;
+    for (; W0 + 64u <= start; W0 += 64u) {
+        const uint32_t p = W0 + (uint32_t)lane;
+        (void)insert(W0, p + kLzMinMatch <= n ? load_u32(in + p) : 0u);
+    }
+
+    uint32_t cover = start;              // first byte not yet produced (uniform)
+    uint32_t cursor = 3, flushed = 0;    // bits placed / whole words written (uniform)
+    unsigned long long accA = 0, accB = 0;
+
+    // ---- software pipeline: own bytes two steps ahead, insertion + candidate gather one step ahead.
+    // Two things keep the loads of step k+1 in flight while step k is parsed and coded (measured: without them the
+    // kernel took 95 ms for cfg5 against the 256-lane form's 48):
+    //   * a value still on its way from memory is never COPIED (the copy would wait for it and for every load issued
+    //     before it): the candidates' bytes live in two register sets used alternately, the loop is unrolled by two,
+    //     and a step's own-bytes prefetch is issued BEFORE its gathers, so that its consumer waits for it alone;
+    //   * every path through a step of the main loop issues the SAME number of loads (a lane without a candidate
+    //     gathers its own position instead), or the compiler could not count them and would drain them all.
+    // The last few steps of a stream (FAST = false) take the guarded forms of everything and need no such care.
+    auto inside16 = [&](uint32_t W) { return n >= 64u + 16u && W <= n - (64u + 16u); };        // every lane has 16 bytes
+    auto inside48 = [&](uint32_t W) { return n >= 64u + 48u && W <= n - (64u + 48u); };        // ... and its candidate 32
+    auto gather_guarded = [&](uint32_t W, uint32_t old, u32x4_unaligned &c0, u32x4_unaligned &c1) {
+        const uint32_t p = W + (uint32_t)lane, c = old - 1u;             // old == 0 -> 0xffffffff: fails c < p
+        c0 = c1 = zero16;
+        if (c < p && p - c <= kLzMaxDist) {
+            const bool in32 = inside48(W);                               // c + 32 <= p + 31 < n
+            c0 = in32 ? load_u128(in + c) : load_16_guarded(in, c, n);
+            c1 = in32 ? load_u128(in + c + 16u) : load_16_guarded(in, c + 16u, n);
+        }
+    };
+    u32x4_unaligned own = load16(W0 + (uint32_t)lane, inside16(W0));
+    uint32_t old = W0 < n ? insert(W0, own.x) : 0u;
+    u32x4_unaligned own1 = W0 + 64u < n && W0 + 64u > W0 ? load16(W0 + 64u + (uint32_t)lane, inside16(W0 + 64u)) : zero16;
+    u32x4_unaligned candA0, candA1, candB0, candB1;
+    gather_guarded(W0, old, candA0, candA1);
+
+    auto step = [&](auto fast_tag, uint32_t W, const u32x4_unaligned &cand0, const u32x4_unaligned &cand1,
+                    u32x4_unaligned &cn0, u32x4_unaligned &cn1) {
+        constexpr bool FAST = decltype(fast_tag)::value;     // W + 336 <= n: this step, the next and the prefetch are inside
+        const uint32_t Wn = W + 64u, Wnn = W + 128u;
+        // stage the next step: its insertions and candidate loads fly while this step is parsed and coded
+        uint32_t old1 = 0;
+        u32x4_unaligned own2 = zero16;
+        if constexpr (FAST) {
+            own2 = load_u128(in + Wnn + (uint32_t)lane);
+            const uint32_t p1 = Wn + (uint32_t)lane;
+            old1 = atomicExch(&sh.head[lz_hash<kQuickHashBits>(own1.x)], p1 + 1u);
+            const uint32_t c1v = old1 - 1u;
+            const uint32_t at = (c1v < p1 && p1 - c1v <= kLzMaxDist) ? c1v : p1;     // no candidate: its own bytes (l = 32, dropped below)
+            cn0 = load_u128(in + at);
+            cn1 = load_u128(in + at + 16u);
+        } else {
+            cn0 = cn1 = zero16;
+            if (Wn < n && Wn > W) {
+                if (Wnn < n && Wnn > Wn) own2 = load16(Wnn + (uint32_t)lane, inside16(Wnn));
+                old1 = insert(Wn, own1.x);
+                gather_guarded(Wn, old1, cn0, cn1);
+            }
+        }
+
+        // ---- probe of this step: up to 32 bytes against the candidate
+        const uint32_t p = W + (uint32_t)lane;
+        const uint32_t maxlen = FAST ? kStdMaxMatch : (p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u);
+        uint32_t len = 0, dist = 0;
+        {
+            // the lane's bytes 16..31 are the first 16 of the lane sixteen positions on: this step's or the next one's.
+            // (Cross-lane reads: executed by ALL lanes, outside any divergent branch.)
+            const u32x4_unaligned a = shfl16(own, (lane + 16) & 63), b = shfl16(own1, (lane + 16) & 63);
+            const u32x4_unaligned mine16 = lane < 48 ? a : b;
+            const uint32_t c = old - 1u;
+            uint32_t l = lz_prefix16(cand0, own);
+            if (l == 16u) l += lz_prefix16(cand1, mine16);
+            l = l < maxlen ? l : maxlen;
+            if (c < p && p - c <= kLzMaxDist) {
+                len = l >= kLzMinMatch ? l : 0u;
+                dist = p - c;
+            }
+        }
+
+        // ---- greedy parse of [W, W + lim), starting at the first byte the previous steps left unproduced
+        const uint32_t lim = FAST ? 64u : ((n - W) < 64u ? (n - W) : 64u);
+        const uint32_t skip = cover > W ? cover - W : 0u;
+        unsigned long long chosen = 0, covered = lz_bits_below(skip < 64u ? skip : 64u);
+        if (skip < lim) {
+            const unsigned long long limmask = FAST ? ~0ull : lz_bits_below(lim);
+            unsigned long long avail = __ballot(len >= kLzMinMatch) & limmask & ~covered;
+            uint32_t end = lim;                                          // first byte after this step's last token
+            while (avail) {
+                const uint32_t m = (uint32_t)__builtin_ctzll(avail);
+                uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)m);
+                if (L >= kLzProbe) {                                     // the probe saturated: measure the rest wave-wide
+                    const uint32_t pabs = W + m;
+                    const uint32_t mlen = FAST ? kStdMaxMatch : ((n - pabs) < kStdMaxMatch ? (n - pabs) : kStdMaxMatch);
+                    if (L < mlen) {
+                        const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
+                        uint32_t rem = mlen - L;
+                        if (rem > 256u) rem = 256u;
+                        L += lz_extend_wave(in + pabs + L, in + pabs - D + L, rem, lane);
+                        if ((uint32_t)lane == m) len = L;
+                    }
+                }
+                chosen |= 1ull << m;
+                const uint32_t e = m + L;
+                if (e >= 64u) {
+                    if (m < 63u) covered |= ~0ull << (m + 1u);
+                    end = e;
+                    break;
+                }
+                covered |= (~0ull << (m + 1u)) & ~(~0ull << e);
+                avail &= ~0ull << e;
+            }
+            cover = W + end;
+            const unsigned long long lits = ~covered & ~chosen & limmask;
+            // ---- code this lane's token, place it
+            const uint32_t byte = own.x & 0xffu;
+            const bool is_match = (chosen >> lane) & 1ull, is_lit = (lits >> lane) & 1ull;
+            uint32_t mcode, mnb, lcode, lnb;
+            static_match(is_match ? len : 3u, is_match ? dist : 1u, mcode, mnb);
+            static_literal(byte, lcode, lnb);
+            const uint32_t code = is_match ? mcode : (is_lit ? lcode : 0u);
+            const uint32_t nb = is_match ? mnb : (is_lit ? lnb : 0u);
+            uint32_t incl = nb;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            if (nb) {
+                const uint32_t at = cursor + incl - nb;
+                const uint32_t word = at >> 5;
+                const unsigned long long wide = (unsigned long long)code << (at & 31u);
+                atomicOr(&sh.ring[word & (kRingWords - 1u)], (uint32_t)wide);
+                atomicOr(&sh.ring[(word + 1) & (kRingWords - 1u)], (uint32_t)(wide >> 32));
+            }
+            cursor += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t full = cursor >> 5;
+            if (full - flushed >= kFlushWords) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const uint32_t cnt = (full - flushed) & ~31u;
+                for (uint32_t i = (uint32_t)lane; i < cnt; i += 64u) {
+                    const uint32_t slot = (flushed + i) & (kRingWords - 1u);
+                    __builtin_nontemporal_store(sh.ring[slot], outw + flushed + i);
+                    sh.ring[slot] = 0;
+                }
+                flushed += cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+        {
+            const uint32_t byte = (p >= start && (FAST || p < n)) ? own.x & 0xffu : 0u;   // the dictionary is not part of the checksum
+            accA += byte;
+            accB += (unsigned long long)(n - p) * byte;
+        }
+        own = own1;
+        own1 = own2;
+        old = old1;
+    };
+    uint32_t W = W0;
+    while (n >= 336u && W <= n - 336u) {
+        step(std::true_type{}, W, candA0, candA1, candB0, candB1);
+        W += 64u;
+        if (!(W <= n - 336u)) {                              // odd number of fast steps: the sets have swapped roles
+            candA0 = candB0;
+            candA1 = candB1;
+            break;
+        }
+        step(std::true_type{}, W, candB0, candB1, candA0, candA1);
+        W += 64u;
+    }
+    for (; W < n && W >= W0; W += 64u) {                     // the last steps of the stream: guarded, no pipeline to keep
+        step(std::false_type{}, W, candA0, candA1, candB0, candB1);
+        candA0 = candB0;
+        candA1 = candB1;
+        if (W + 64u < W) break;
+    }
+
+    // ---- everything that is left in the ring, the end-of-block code, the optional sync marker
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    {
+        const uint32_t full = cursor >> 5;
+        for (uint32_t i = flushed + (uint32_t)lane; i < full; i += 64u) {
+            __builtin_nontemporal_store(sh.ring[i & (kRingWords - 1u)], outw + i);
+        }
+        flushed = full;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        accA += __shfl_xor(accA, m, 64);
+        accB += __shfl_xor(accB, m, 64);
+    }
+    if (lane == 0) {
+        uint8_t *outb = job.out;
+        uint32_t cbits = (cursor & 31u) + 7u;                // the partial word + EOB (seven 0 bits, trees_emit.h:169-180)
+        uint32_t cw = sh.ring[(cursor >> 5) & (kRingWords - 1u)];
+        uint32_t wbase = flushed;
+        if (cbits >= 32) {
+            outw[wbase++] = cw;
+            cw = 0;
+            cbits -= 32;
+        }
+        uint32_t bytes = wbase * 4u;
+        const bool sync = !final_block && (job.flags & ZNG_ROCM_BLOCK_SYNC_FLUSH) != 0;
+        if (sync) cbits += 3;                                // header of an empty stored block: BFINAL = 0, BTYPE = 00
+        for (uint32_t k = 0; k < (cbits + 7u) / 8u; ++k) outb[bytes++] = (uint8_t)((unsigned long long)cw >> (8 * k));
+        if (sync) {                                          // deflate.c:1064-1076
+            outb[bytes++] = 0x00;
+            outb[bytes++] = 0x00;
+            outb[bytes++] = 0xff;
+            outb[bytes++] = 0xff;
+        }
+        const unsigned long long A = accA % kAdlerBase, B = accB % kAdlerBase;
+        results[2 * blockIdx.x] = bytes;
+        results[2 * blockIdx.x + 1] = (uint32_t)(((1 + A) % kAdlerBase) | ((((unsigned long long)(n - start) + B) % kAdlerBase) << 16));
+    }
+}
+
 }  // namespace zr
 
 using namespace zr;
@@ -282,7 +547,13 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     }
     ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(StreamJobDev), hipMemcpyHostToDevice, st));
     if (int rc = host_tables_release(ws, st)) return rc;
-    ZR_LAUNCH_TRACED(deflate_quick_kernel, dim3((unsigned)njobs), dim3(256), st, d_jobs, d_results);
+    // Four waves per stream is the form that ships.  The one-wave-per-stream form (no barriers, 18 KiB of LDS per wave)
+    // measured slower on every stream count tried (both forms are instruction-issue bound, and
+    // two waves per SIMD cover less latency than eight); ZNG_ROCM_QUICK_FORM=wave selects it for measurements.
+    bool wave_form = false;
+    if (const char *f = getenv("ZNG_ROCM_QUICK_FORM")) wave_form = f[0] == 'w';
+    if (wave_form) ZR_LAUNCH_TRACED(deflate_quick_wave_kernel, dim3((unsigned)njobs), dim3(64), st, d_jobs, d_results);
+    else ZR_LAUNCH_TRACED(deflate_quick_kernel, dim3((unsigned)njobs), dim3(256), st, d_jobs, d_results);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }
