@@ -75,22 +75,19 @@ int main(int argc, char **argv) {
 
     const Run runs[] = {
         {"adler32", launcher<true, false, 0, false>, false, true, false},
+        {"adler32 V=4096 DPP reductions", launcher<true, false, 4096, false>, false, true, false},
         {"crc32 V=0 (round-1 form)", launcher<false, true, 0, false>, true, false, false},
-        {"crc32 V=194 built, 4 rows early", launcher<false, true, 194, false>, true, false, false},
-        {"crc32 V=194+256 no rows early", launcher<false, true, 194 + 256, false>, true, false, false},
-        {"crc32 V=194+512 one row early", launcher<false, true, 194 + 512, false>, true, false, false},
-        {"crc32 V=194+768 two rows early", launcher<false, true, 194 + 768, false>, true, false, false},
-        {"crc32 V=195+256 none early, both bufs after", launcher<false, true, 195 + 256, false>, true, false, false},
-        {"crc32 V=195+512 one early, both bufs after", launcher<false, true, 195 + 512, false>, true, false, false},
-        {"crc32 V=195+768 two early, both bufs after", launcher<false, true, 195 + 768, false>, true, false, false},
-        {"fused V=0", launcher<true, true, 0, false>, true, true, false},
+        {"crc32 V=194 built, lds barrier, x32 fold", launcher<false, true, 194, false>, true, false, false},
+        {"crc32 V=1218 + byte-addressed image", launcher<false, true, 1218, false>, true, false, false},
+        {"crc32 V=3266 + direct image, one barrier", launcher<false, true, 3266, false>, true, false, false},
+        {"crc32 V=7362 + two-level weights, DPP", launcher<false, true, 7362, false>, true, false, false},
+        {"crc32 V=7362+32 no lane multiply (timing only)", launcher<false, true, 7362 + 32, false>, true, false, false},
         {"fused V=194", launcher<true, true, 194, false>, true, true, false},
-        {"fused V=194+512", launcher<true, true, 194 + 512, false>, true, true, false},
-        {"fused V=195+512", launcher<true, true, 195 + 512, false>, true, true, false},
-        {"crc32 V=194 PROFILE", launcher<false, true, 194, true>, true, false, true},
-        {"crc32 V=194+256 PROFILE", launcher<false, true, 194 + 256, true>, true, false, true},
-        {"crc32 V=194+512 PROFILE", launcher<false, true, 194 + 512, true>, true, false, true},
-        {"crc32 V=195+512 PROFILE", launcher<false, true, 195 + 512, true>, true, false, true},
+        {"fused V=3266", launcher<true, true, 3266, false>, true, true, false},
+        {"fused V=7362", launcher<true, true, 7362, false>, true, true, false},
+        {"adler32 V=4096 PROFILE", launcher<true, false, 4096, true>, false, true, true},
+        {"crc32 V=3266 PROFILE", launcher<false, true, 3266, true>, true, false, true},
+        {"crc32 V=7362 PROFILE", launcher<false, true, 7362, true>, true, false, true},
     };
 
     const int WARM = 300, REPS = 200;

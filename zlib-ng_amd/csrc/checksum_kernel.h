@@ -75,6 +75,75 @@ __device__ __forceinline__ uint32_t braid_step(const uint32_t *lut, uint32_t rep
     return r0 ^ r1 ^ r2 ^ r3 ^ w;
 }
 
+// a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler does not form it by itself
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+// (a & b) ^ c
+__device__ __forceinline__ uint32_t and_xor(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x6a);
+}
+
+// Byte-addressed form of the same step (kVarByteAddr).  The main loop is bound by vector-instruction issue, not by LDS
+// or HBM: the form above spends bfe + shift-or on every lookup address (48 vector instructions per 16-byte piece, 16 of
+// them XORs).  Here the table image is laid out so that the index is exactly BYTE 1 of the LDS byte address:
+//     address = (k >> 1) * 65536 + e * 256 + (k & 1) * 128 + (lane & 31) * 4       (table k, entry e)
+// (still 128 KiB, still bank = lane % 32), so one SDWA move that writes byte k of the state into byte 1 of a
+// lane-constant address register (dst_unused:UNUSED_PRESERVE keeps the other three bytes) IS the address computation:
+// 16 moves + 8 three-input XORs = 24 vector instructions per piece.  The four address registers live across the loop;
+// each is rewritten only after the ds_read that used it has been issued (DS reads its address at issue).
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+template <int K>
+__device__ __forceinline__ void put_index_byte(uint32_t &addr, uint32_t s) {
+    if constexpr (K == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(addr) : "v"(s));
+    if constexpr (K == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(addr) : "v"(s));
+    if constexpr (K == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(addr) : "v"(s));
+    if constexpr (K == 3) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(addr) : "v"(s));
+}
+struct BraidAddr {
+    uint32_t a0, a1, a2, a3;      // LDS byte addresses of entry 0 of tables 0..3 for this lane; byte 1 is the index slot
+};
+__device__ __forceinline__ uint32_t braid_step_bytes(BraidAddr &A, uint32_t s, uint32_t w) {
+    put_index_byte<0>(A.a0, s);
+    const uint32_t r0 = *(lds_u32_ptr)(uintptr_t)A.a0;
+    put_index_byte<1>(A.a1, s);
+    const uint32_t r1 = *(lds_u32_ptr)(uintptr_t)A.a1;
+    put_index_byte<2>(A.a2, s);
+    const uint32_t r2 = *(lds_u32_ptr)(uintptr_t)A.a2;
+    put_index_byte<3>(A.a3, s);
+    const uint32_t r3 = *(lds_u32_ptr)(uintptr_t)A.a3;
+    return xor3(xor3(r0, r1, r2), r3, w);
+}
+
+// XOR / sum of a value over the 64 lanes of the wave, returned wave-uniform.  Four DPP steps (lane permutes inside the
+// vector ALU, no LDS round trip as with ds_bpermute) leave every 16-lane row holding its row total; four readlanes
+// combine the rows on the scalar unit.
+template <bool XOR>
+__device__ __forceinline__ uint32_t wave_reduce(uint32_t v) {
+    auto op = [](uint32_t a, uint32_t b) { return XOR ? (a ^ b) : (a + b); };
+    v = op(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v = op(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v = op(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));   // row_mirror
+    return op(op((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+              op((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
+// r * w from w's 32 partial products held four to a 16-byte LDS row (rows kq * stride + idx): bit 31 of r is the x^0
+// coefficient (mulmod, gf2.h).
+__device__ __forceinline__ uint32_t mul_by_rows(const uint4 *rows, int stride, int idx, uint32_t r) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const uint4 a = rows[kq * stride + idx];
+        acc = and_xor((uint32_t)__builtin_amdgcn_sbfe((int)r, 31 - 4 * kq, 1), a.x, acc);
+        acc = and_xor((uint32_t)__builtin_amdgcn_sbfe((int)r, 30 - 4 * kq, 1), a.y, acc);
+        acc = and_xor((uint32_t)__builtin_amdgcn_sbfe((int)r, 29 - 4 * kq, 1), a.z, acc);
+        acc = and_xor((uint32_t)__builtin_amdgcn_sbfe((int)r, 28 - 4 * kq, 1), a.w, acc);
+    }
+    return acc;
+}
+
 // What the CRC prologue needs to BUILD its tables in registers instead of fetching them: entry e of a table that is
 // linear over GF(2) is the XOR of the entries of e's set bits, so eight words per table suffice.  They travel as
 // kernel arguments (scalar loads from the kernarg segment): the prologue touches no table in HBM at all -- measured,
@@ -105,21 +174,32 @@ constexpr int kVarNoReplicate = 16;   // TIMING ONLY (wrong CRC): skip the 128 K
 constexpr int kVarNoMultiply  = 32;   // TIMING ONLY (wrong CRC): skip the per-lane weight multiply
 constexpr int kVarBuildTables = 64;   // build the table entries in registers from CrcBits: no table fetch in the prologue
 constexpr int kVarLdsBarrier  = 128;  // prologue barriers wait for LDS only, not for the data loads already in flight
+constexpr int kVarByteAddr    = 1024; // table image with the index in byte 1 of the LDS address: one SDWA move per lookup
+                                      //   address, three-input XORs (braid_step_bytes) -- 24 instead of 48 VALU per piece
+constexpr int kVarDirectImage = 2048; // every lane computes the eight image entries it stores straight from CrcBits: no staging
+                                      //   copy of the stride tables, ONE prologue barrier (needs kVarBuildTables|kVarByteAddr|kVarFoldX32)
+constexpr int kVarTreeEpilogue = 4096; // lane weights in two levels (lane-in-wave from LDS, then wave) instead of 32 loads per lane;
+                                      //   DPP wave reductions; the group-weight multiplies spread over the lanes of wave 0
 constexpr int kVarEarlyRows   = 768;  // two bits: how many rows of group 0 are requested BEFORE the table build when
                                       //   kVarBuildTables is on: 0 -> all (4), 256 -> none, 512 -> one, 768 -> two
 // Measured on MI355X (tools/micro/crc_phases.hip, profiles/r02_crc_phases.md), crc32 over 64 MiB, dispatch time:
-// round-1 form 17.9 us; this combination 17.05 us.  Requesting the second buffer, more rows, or the lane products
-// before the table work made it SLOWER: a CU accepts only so many loads in flight, the wave stalls at issue.
-constexpr int kCrcVariant = kVarFoldX32 | kVarBuildTables | kVarLdsBarrier;
+// round-1 form 17.9 us; fold + built tables + LDS barriers 17.1 us; byte-addressed image 15.9 us; direct image 15.5 us;
+// two-level weights and DPP reductions 14.0 us (0.60 of the 8 TB/s peak; Adler-32 alone 11.3 us).  Requesting the second
+// buffer, more rows, or the lane products before the table work made it SLOWER: a CU accepts only so many loads in
+// flight, the wave stalls at issue.
+constexpr int kCrcVariant = kVarFoldX32 | kVarBuildTables | kVarLdsBarrier | kVarByteAddr | kVarDirectImage | kVarTreeEpilogue;
 
 // DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
 template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false, int UNROLL = 4>
 __global__ __launch_bounds__(kWgThreads)
 void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
-    __shared__ uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
+    // 64 KiB alignment: with kVarByteAddr byte 1 of a lookup address must be free for the index (braid_step_bytes)
+    __shared__ __attribute__((aligned(65536))) uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
     // linear copies: the four stride tables, the byte table, the four x^32 tables
     __shared__ uint32_t stage[DO_CRC ? 4 * 256 + 256 + 4 * 256 : 4];
     __shared__ uint32_t red[3][kWgThreads / 64];
+    constexpr bool TREE = (V & kVarTreeEpilogue) != 0;
+    __shared__ uint4 tree_rows[(DO_CRC && TREE) ? 640 : 1];
 
     const int t = threadIdx.x;
     const uint32_t rep = t & 31;
@@ -153,6 +233,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     bool b_requested = false;            // bufB already holds group 1
     uint32_t group_w0 = 0, group_w1 = 0;
     uint32_t part[32];                   // the lane's 32 partial products (epilogue multiply)
+    uint4 tree_row = make_uint4(0, 0, 0, 0);   // kVarTreeEpilogue: this thread's row of tabs->tree_pp, stashed in LDS later
     if constexpr (DO_CRC) {
         // the two digits of this group's end-of-body weight (epilogue, thread 0): fetched now, not on the tail
         const unsigned long long k_after = (unsigned long long)(args.nunits - u_hi);
@@ -172,6 +253,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             }
             group_w0 = tabs->unit_pow[0][k_after & 1023u];
             group_w1 = tabs->unit_pow[1][(k_after >> 10) & 1023u];
+            if constexpr (TREE) tree_row = *reinterpret_cast<const uint4 *>(tabs->tree_pp[t]);
             if constexpr ((V & kVarEarlyPow) != 0) {
 #pragma unroll
                 for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
@@ -180,20 +262,49 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             // first 256 lanes one byte-table entry each (the shift register of tools/makecrct.c:66-73)
             const int k = __builtin_amdgcn_readfirstlane(t >> 8);
             const uint32_t e = (uint32_t)t & 255u;
-            uint32_t sv = 0, xv = 0;
+            if constexpr ((V & kVarDirectImage) != 0) {
+                static_assert((V & kVarDirectImage) == 0 || ((V & kVarByteAddr) != 0 && (V & kVarFoldX32) != 0),
+                              "direct image: byte-addressed layout and x^32 fold only");
+                // The image straight from the bit words: lane t stores quarter t % 8 (four replicas, one b128) of the
+                // 128-byte slots of the eight entries {table j, index h * 128 + t / 8}.  The low seven index bits are the
+                // lane's own, so a table costs seven and-xor steps for both halves (bit 7 = one more XOR): 39 vector
+                // instructions, no staging copy, and each wave can start the moment it is launched -- the workgroup's
+                // 16 waves arrive over ~1.1 us, and a barrier in front of the image made every wave wait for the last.
+                uint32_t m[7];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t m = 0u - ((e >> i) & 1u);
-                sv ^= args.bits.stride[k][i] & m;
-                xv ^= args.bits.x32[k][i] & m;
-            }
-            stage[t] = sv;
-            stage[1280 + t] = xv;
-            if (t < 256) {
-                uint32_t r = e;
+                for (int b = 0; b < 7; ++b) m[b] = (uint32_t)__builtin_amdgcn_sbfe((int)((uint32_t)t >> 3), b, 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) r = (r >> 1) ^ (kCrcPoly & (0u - (r & 1u)));
-                stage[1024 + t] = r;
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 7; ++b) v = and_xor(m[b], args.bits.stride[j][b], v);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t vv = h ? v ^ args.bits.stride[j][7] : v;
+                        const int slot = (j >> 1) * 512 + ((h * 128 + (t >> 3)) << 1) + (j & 1);
+                        reinterpret_cast<uint4 *>(lut)[slot * 8 + (t & 7)] = make_uint4(vv, vv, vv, vv);
+                    }
+                }
+                uint32_t xv = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv = and_xor((uint32_t)__builtin_amdgcn_sbfe((int)e, i, 1), args.bits.x32[k][i], xv);
+                stage[1280 + t] = xv;
+            } else {
+                uint32_t sv = 0, xv = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t m = 0u - ((e >> i) & 1u);
+                    sv ^= args.bits.stride[k][i] & m;
+                    xv ^= args.bits.x32[k][i] & m;
+                }
+                stage[t] = sv;
+                stage[1280 + t] = xv;
+                if (t < 256) {
+                    uint32_t r = e;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) r = (r >> 1) ^ (kCrcPoly & (0u - (r & 1u)));
+                    stage[1024 + t] = r;
+                }
             }
         } else {
             // tables: HBM/L2 -> LDS once (9 KiB, one dwordx4 per lane of the first 9 waves)
@@ -220,16 +331,25 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             }
             if (t < 576) reinterpret_cast<uint4 *>(stage)[t] = tab;
         }
-        if constexpr ((V & kVarLdsBarrier) != 0) lds_barrier();
-        else __syncthreads();
+        if constexpr ((V & kVarDirectImage) == 0) {
+            if constexpr ((V & kVarLdsBarrier) != 0) lds_barrier();
+            else __syncthreads();
+        }
         stamp(1);
         // replicated LDS -> LDS: 32768 dwords, lane-consecutive writes; the 32 replicas of one entry are 32 adjacent
         // dwords: eight lanes write one entry, four replicas (one b128) each
-        if constexpr ((V & kVarNoReplicate) == 0) {
+        if constexpr ((V & kVarNoReplicate) == 0 && (V & kVarDirectImage) == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                // entry E = i * 128 + t / 8 = table i / 2, index (i & 1) * 128 + t / 8
                 const uint32_t v = stage[i * 128 + (t >> 3)];
-                reinterpret_cast<uint4 *>(lut)[i * kWgThreads + t] = make_uint4(v, v, v, v);
+                if constexpr ((V & kVarByteAddr) != 0) {
+                    // 128-byte slot number (i / 4) * 512 + index * 2 + (table & 1); eight b128 per slot
+                    const int slot = (i >> 2) * 512 + (((i & 1) * 128 + (t >> 3)) << 1) + ((i >> 1) & 1);
+                    reinterpret_cast<uint4 *>(lut)[slot * 8 + (t & 7)] = make_uint4(v, v, v, v);
+                } else {
+                    reinterpret_cast<uint4 *>(lut)[i * kWgThreads + t] = make_uint4(v, v, v, v);
+                }
             }
         }
         if constexpr ((V & kVarLdsBarrier) != 0) lds_barrier();
@@ -253,40 +373,65 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     stamp(2);
 
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;             // CRC braids
+    BraidAddr braid_addr;
+    if constexpr (DO_CRC && (V & kVarByteAddr) != 0) {
+        const uint32_t base = (uint32_t)(uintptr_t)(lds_u32_ptr)lut + rep * 4u;
+        if ((base & 0xff00u) != 0) __builtin_trap();     // the image is not where the address arithmetic needs it
+        braid_addr.a0 = base;
+        braid_addr.a1 = base + 128u;
+        braid_addr.a2 = base + 65536u;
+        braid_addr.a3 = base + 65536u + 128u;
+    }
     uint32_t S1 = 0, SR = 0, SW = 0;                     // Adler: byte sum, prefix-of-sums, in-piece weights
-    unsigned long long accA = 0, accB = 0;               // Adler, reduced mod BASE between batches
+    uint32_t accA = 0, accB = 0;                         // Adler, reduced mod BASE between batches
     int batch = 0;
 
     auto fold_adler = [&](long long off_last) {
         // B over the batch = sum_k (n - o_k - 16) * A_k + W_k, o_k = piece offset relative to buf.
         // With pieces one unit apart:  (n - o_last - 16) * S1 + U * SR + SW  (all terms >= 0).
-        unsigned long long lead = (unsigned long long)(args.n - (off_last - args.head) - kPieceBytes);
-        unsigned long long v = (lead % kAdlerBase) * S1 + (unsigned long long)kUnitBytes * SR + SW;
+        // Everything mod BASE in 32-bit arithmetic: the lead term is wave-uniform up to the lane's 16 t, so its 64-bit
+        // reduction runs once on the scalar unit; the 64-bit form cost three software divisions per lane on the tail.
+        const unsigned long long off0 = (unsigned long long)(off_last - (long long)t * kPieceBytes);
+        const unsigned long long off0_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(off0 >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off0);
+        const uint32_t lead0 = (uint32_t)((unsigned long long)(args.n - ((long long)off0_u - args.head) - kPieceBytes) % kAdlerBase);
+        const uint32_t back = (uint32_t)t * (uint32_t)kPieceBytes;          // < 16384 < BASE
+        const uint32_t lead = lead0 >= back ? lead0 - back : lead0 + kAdlerBase - back;
+        const uint32_t s1m = S1 % kAdlerBase;
+        uint32_t v = (lead * s1m) % kAdlerBase;                             // < 65521^2 < 2^32
+        v += ((uint32_t)kUnitBytes * (SR % kAdlerBase)) % kAdlerBase;       // 16384 * 65520 < 2^30
+        v += SW % kAdlerBase;
         accB = (accB + v) % kAdlerBase;
-        accA = (accA + S1) % kAdlerBase;
+        accA = (accA + s1m) % kAdlerBase;
         S1 = SR = SW = 0;
         batch = 0;
     };
 
     auto consume = [&](uint4 v) {
         if constexpr (DO_CRC) {
-            s0 = braid_step(lut, rep, s0, v.x);
-            s1 = braid_step(lut, rep, s1, v.y);
-            s2 = braid_step(lut, rep, s2, v.z);
-            s3 = braid_step(lut, rep, s3, v.w);
+            if constexpr ((V & kVarByteAddr) != 0) {
+                s0 = braid_step_bytes(braid_addr, s0, v.x);
+                s1 = braid_step_bytes(braid_addr, s1, v.y);
+                s2 = braid_step_bytes(braid_addr, s2, v.z);
+                s3 = braid_step_bytes(braid_addr, s3, v.w);
+            } else {
+                s0 = braid_step(lut, rep, s0, v.x);
+                s1 = braid_step(lut, rep, s1, v.y);
+                s2 = braid_step(lut, rep, s2, v.z);
+                s3 = braid_step(lut, rep, s3, v.w);
+            }
         }
         if constexpr (DO_ADLER) {
-            uint32_t a = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
-            a = __builtin_amdgcn_sad_u8(v.y, 0u, a);
-            a = __builtin_amdgcn_sad_u8(v.z, 0u, a);
-            a = __builtin_amdgcn_sad_u8(v.w, 0u, a);
-            uint32_t w = __builtin_amdgcn_udot4(v.x, 0x0D0E0F10u, 0u, false);   // weights 16,15,14,13
-            w = __builtin_amdgcn_udot4(v.y, 0x090A0B0Cu, w, false);            // 12..9
-            w = __builtin_amdgcn_udot4(v.z, 0x05060708u, w, false);            // 8..5
-            w = __builtin_amdgcn_udot4(v.w, 0x01020304u, w, false);            // 4..1
+            // the running sums ride in the accumulator operand: nine vector instructions per piece
             SR += S1;
-            S1 += a;
-            SW += w;
+            S1 = __builtin_amdgcn_sad_u8(v.x, 0u, S1);
+            S1 = __builtin_amdgcn_sad_u8(v.y, 0u, S1);
+            S1 = __builtin_amdgcn_sad_u8(v.z, 0u, S1);
+            S1 = __builtin_amdgcn_sad_u8(v.w, 0u, S1);
+            SW = __builtin_amdgcn_udot4(v.x, 0x0D0E0F10u, SW, false);          // weights 16,15,14,13
+            SW = __builtin_amdgcn_udot4(v.y, 0x090A0B0Cu, SW, false);          // 12..9
+            SW = __builtin_amdgcn_udot4(v.z, 0x05060708u, SW, false);          // 8..5
+            SW = __builtin_amdgcn_udot4(v.w, 0x01020304u, SW, false);          // 4..1
         }
     };
 
@@ -411,11 +556,14 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
                     r ^= c == 0 ? s1 : (c == 1 ? s2 : s3);
                 }
             }
-            // r * (this lane's weight): the 32 partial products weight * x^k come from a table (32 lane-consecutive
-            // loads in flight together) instead of a 32-step shift-and-reduce loop.  Bit 31 of r is the x^0 coefficient.
+            // r * (this lane's weight)
             if constexpr ((V & kVarNoMultiply) != 0) {
                 pc = r;
+            } else if constexpr (TREE) {
+                pc = r;                 // multiplied below, behind the barrier that publishes tree_rows
             } else {
+                // the 32 partial products weight * x^k come from a table (32 lane-consecutive loads in flight together)
+                // instead of a 32-step shift-and-reduce loop.  Bit 31 of r is the x^0 coefficient.
                 if constexpr ((V & kVarEarlyPow) == 0) {
 #pragma unroll
                     for (int k = 0; k < 32; ++k) part[k] = tabs->lane_pow[k][t];
@@ -425,46 +573,110 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
             }
         }
     }
-    stamp(4);
-    uint32_t pa = (uint32_t)accA, pb = (uint32_t)accB;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        if constexpr (DO_CRC) pc ^= __shfl_xor(pc, m, 64);
-        if constexpr (DO_ADLER) {
-            pa += __shfl_xor(pa, m, 64);
-            pb += __shfl_xor(pb, m, 64);
-        }
-    }
     const int wave = t >> 6;
-    if ((t & 63) == 0) {
-        red[0][wave] = pc;
-        red[1][wave] = pa;     // <= 64 * 65520
-        red[2][wave] = pb;
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t c = 0;
-        unsigned long long a = 0, b = 0;
-        for (int w = 0; w < kWgThreads / 64; ++w) {
-            c ^= red[0][w];
-            a += red[1][w];
-            b += red[2][w];
-        }
-        // Weight this group's CRC to the end of the body: x^(8 * U * units_after), two table digits.  The
-        // common factor x^(8 * tail bytes) is applied once, by the last group.
+    const int lane = t & 63;
+    if constexpr (TREE) {
+        // Two-level lane weights.  Lane t = 64 w + l weighs (lane l of the last wave) * x^(8 * 1024 * (15 - w)): the first
+        // factor's partial products are the same 8 KiB for every wave and come from LDS (8 x ds_read_b128 per lane; the
+        // 32 loads per lane of the one-level form were 128 KiB per workgroup through the texture path, ~1.2 us), the second
+        // is applied to the 16 wave results by 16 lanes of wave 0.
+        uint32_t gpp = 0;
         if constexpr (DO_CRC) {
-            const unsigned long long k = (unsigned long long)(args.nunits - u_hi);
-            if (c && k) {
-                c = mulmod(c, group_w0);
-                if (k >> 10) c = mulmod(c, group_w1);
+            if (t < 640) tree_rows[t] = tree_row;
+            // wave 0 is the first to get here and waits for the slowest wave anyway: it uses the time to spread the two
+            // group-weight factors into their partial products, lane j: w0 * x^j, lane 32 + j: w1 * x^j
+            if (wave == 0) {
+                gpp = lane < 32 ? group_w0 : group_w1;
+                const int steps = lane & 31;
+                for (int i = 0; i < 31; ++i) {
+                    const uint32_t nx = (gpp >> 1) ^ (kCrcPoly & (0u - (gpp & 1u)));
+                    gpp = i < steps ? nx : gpp;
+                }
+            }
+            lds_barrier();
+            if constexpr ((V & kVarNoMultiply) == 0) pc = mul_by_rows(tree_rows, 64, lane, pc);
+        }
+        stamp(4);
+        uint32_t wc = 0, wa = 0, wb = 0;
+        if constexpr (DO_CRC) wc = wave_reduce<true>(pc);
+        if constexpr (DO_ADLER) {
+            wa = wave_reduce<false>(accA);      // <= 64 * 65520
+            wb = wave_reduce<false>(accB);
+        }
+        if (lane == 0) {
+            red[0][wave] = wc;
+            red[1][wave] = wa;
+            red[2][wave] = wb;
+        }
+        lds_barrier();
+        if (wave == 0) {
+            uint32_t c = 0, a = 0, b = 0;
+            if constexpr (DO_CRC) {
+                uint32_t v = lane < 16 ? red[0][lane & 15] : 0u;
+                v = mul_by_rows(tree_rows + 512, 16, lane & 15, v);
+                c = wave_reduce<true>(v);
+                // Weight the group's CRC to the end of the body: c * x^(8 * U * units_after) = c * w0 * w1 (two table
+                // digits; digit 0 is x^0, so no case split).  The common factor x^(8 * tail bytes) is applied once, by the
+                // finalize kernel.  Each multiply = one masked term per lane + a wave reduction (a 32-step dependent
+                // shift-and-reduce loop on one lane took ~0.5 us each).
+                const uint32_t sel = 31u - (uint32_t)(lane & 31);
+                c = wave_reduce<true>(lane < 32 ? gpp & (0u - ((c >> sel) & 1u)) : 0u);
+                c = wave_reduce<true>(lane >= 32 ? gpp & (0u - ((c >> sel) & 1u)) : 0u);
+            }
+            if constexpr (DO_ADLER) {
+                a = wave_reduce<false>(lane < 16 ? red[1][lane & 15] : 0u);     // <= 1024 * 65520 < 2^27
+                b = wave_reduce<false>(lane < 16 ? red[2][lane & 15] : 0u);
+            }
+            if (lane == 0) {
+                Partial pt;
+                pt.crc = c;                               // already weighted to the end of the body
+                pt.a = a % kAdlerBase;
+                pt.b = b % kAdlerBase;
+                pt.pad = 0;
+                partials[g] = pt;
             }
         }
-        Partial pt;
-        pt.crc = c;                                   // already weighted to the end of the body
-        pt.a = (uint32_t)(a % kAdlerBase);
-        pt.b = (uint32_t)(b % kAdlerBase);
-        pt.pad = 0;
-        partials[g] = pt;
+    } else {
+        stamp(4);
+        uint32_t pa = accA, pb = accB;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            if constexpr (DO_CRC) pc ^= __shfl_xor(pc, m, 64);
+            if constexpr (DO_ADLER) {
+                pa += __shfl_xor(pa, m, 64);
+                pb += __shfl_xor(pb, m, 64);
+            }
+        }
+        if ((t & 63) == 0) {
+            red[0][wave] = pc;
+            red[1][wave] = pa;     // <= 64 * 65520
+            red[2][wave] = pb;
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t c = 0;
+            unsigned long long a = 0, b = 0;
+            for (int w = 0; w < kWgThreads / 64; ++w) {
+                c ^= red[0][w];
+                a += red[1][w];
+                b += red[2][w];
+            }
+            // Weight this group's CRC to the end of the body: x^(8 * U * units_after), two table digits.  The
+            // common factor x^(8 * tail bytes) is applied once, by the last group.
+            if constexpr (DO_CRC) {
+                const unsigned long long k = (unsigned long long)(args.nunits - u_hi);
+                if (c && k) {
+                    c = mulmod(c, group_w0);
+                    if (k >> 10) c = mulmod(c, group_w1);
+                }
+            }
+            Partial pt;
+            pt.crc = c;                                   // already weighted to the end of the body
+            pt.a = (uint32_t)(a % kAdlerBase);
+            pt.b = (uint32_t)(b % kAdlerBase);
+            pt.pad = 0;
+            partials[g] = pt;
+        }
     }
     stamp(5);
 }

@@ -31,6 +31,10 @@ struct DeviceTables {
                                          //   partial products of the epilogue's per-lane GF(2) multiply, precomputed
     uint32_t x32_tab[4][256];            // byte k of a word -> times x^32 (the fold of one braid into the next, one
                                          //   LDS latency instead of four dependent byte-table steps)
+    uint32_t tree_pp[1024][4];           // two-level form of the lane weights, as the 16-byte rows the epilogue stashes in LDS:
+                                         //   rows 0..511   [kq * 64 + l]: (weight of lane l of the LAST wave) * x^(4kq+j), j = 0..3
+                                         //   rows 512..639 [kq * 16 + w]: x^(8 * 1024 * (15 - w)) * x^(4kq+j): wave w -> last wave
+                                         //   rows 640..1023: zero (every thread loads one row, no branch around the load)
 };
 
 struct Partial {            // one per workgroup, written by the streaming kernel

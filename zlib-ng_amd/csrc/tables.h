@@ -40,6 +40,19 @@ inline void build_tables(DeviceTables &t) {
             b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));                  // times x, reflected representation
         }
     }
+    // two-level lane weights: lane t = 64 w + l weighs x^(8*(16*(63-l)+4)) [= the last wave's lane weight] times
+    // x^(8*1024*(15-w)); each with its 32 partial products, four per 16-byte row
+    for (int i = 0; i < 1024; ++i)
+        for (int j = 0; j < 4; ++j) t.tree_pp[i][j] = 0;
+    for (int l = 0; l < 64; ++l)
+        for (int k = 0; k < 32; ++k) t.tree_pp[(k >> 2) * 64 + l][k & 3] = t.lane_pow[k][kWgThreads - 64 + l];
+    for (int w = 0; w < 16; ++w) {
+        uint32_t b = xpow_bits(8ull * 1024ull * (uint64_t)(15 - w));
+        for (int k = 0; k < 32; ++k) {
+            t.tree_pp[512 + (k >> 2) * 16 + w][k & 3] = b;
+            b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         uint32_t step = xpow_bits(8ull * (uint64_t)kUnitBytes << (10 * i));   // x^(8 * U * 1024^i)
         uint32_t cur = 0x80000000u;
