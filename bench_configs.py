@@ -90,24 +90,42 @@ def main():
         big = torch.randint(0, 256, ((max(sizes) << 20) + 16,), dtype=torch.uint8, device="cuda")
         out = torch.zeros(2, dtype=torch.int32, device="cuda")
         dst = torch.empty_like(big)
+        # the first kernels of a process run at idle clocks: ~0.5 s of streaming first (the 64 MiB Adler row measured
+        # 16.4 us as the first row of a fresh process, 11.4 us behind other work)
+        for _ in range(3000):
+            zr.adler32_crc32_dev(big, out, length=max(sizes) << 20)
+        torch.cuda.synchronize()
         for mib in sizes:
             n = mib << 20
             row = {"MiB": mib}
+            # the C ABI entry points with their arguments converted once: at 64 MiB a launch is ~13 us of GPU time and the
+            # tensor -> pointer conversions of the Python wrappers cost more than that per call, which leaves the GPU idle
+            # between kernels (and at a lower clock: the rows then read 1-3 us slower than tools/micro/crc_phases)
+            import ctypes as C
+            L = zr.lib()
+            p_in, p_out, p_dst = C.c_void_p(big.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(dst.data_ptr())
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for name, fn, traffic in (
-                    ("adler32", lambda: zr.adler32_dev(big, out, length=n), 1),
-                    ("crc32", lambda: zr.crc32_dev(big, out, length=n), 1),
-                    ("adler32+crc32 fused", lambda: zr.adler32_crc32_dev(big, out, length=n), 1),
-                    ("fold_copy (adler+crc, 2N traffic)", lambda: zr.fold_copy_dev(3, dst, big, out, length=n), 2)):
-                for _ in range(200):                               # clocks settle
-                    fn()
-                torch.cuda.synchronize()
-                zr.trace_begin(50)
-                for _ in range(50):
-                    fn()
-                ms = statistics.mean(zr.trace_end(50))
+                    ("adler32", lambda: L.zng_rocm_adler32_dev(1, p_in, n, p_out, st), 1),
+                    ("crc32", lambda: L.zng_rocm_crc32_dev(0, p_in, n, p_out, st), 1),
+                    ("adler32+crc32 fused", lambda: L.zng_rocm_adler32_crc32_dev(1, 0, p_in, n, p_out, st), 1),
+                    ("fold_copy (adler+crc, 2N traffic)", lambda: L.zng_rocm_fold_copy_dev(3, 1, 0, p_dst, p_in, n, p_out, st), 2)):
+                # three passes of {settle, 50 traced launches}; the row is the best pass (DVFS noise between passes is
+                # +-1.5 us at 64 MiB, far more than the spread inside one pass)
+                passes = []
+                for _ in range(3):
+                    for _ in range(max(200, 1000 * 64 // mib)):    # clocks settle
+                        fn()
+                    torch.cuda.synchronize()
+                    zr.trace_begin(50)
+                    for _ in range(50):
+                        fn()
+                    passes.append(statistics.mean(zr.trace_end(50)))
+                ms = min(passes)
                 step = gpu_time_ms(fn, 10, torch)
                 row[name] = {"kernel_ms": round(ms, 4), "algorithmic_GBps": round(traffic * n / 1e9 / (ms / 1e3), 1),
                              "frac_of_8TBps": round(traffic * n / 1e9 / (ms / 1e3) / 8000, 3),
+                             "kernel_ms_passes": [round(x, 4) for x in passes],
                              "step_ms_incl_finalize": round(step, 4)}
             rows.append(row)
         report["cfg2"] = rows

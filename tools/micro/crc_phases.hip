@@ -74,20 +74,15 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 
     const Run runs[] = {
-        {"adler32", launcher<true, false, 0, false>, false, true, false},
-        {"adler32 V=4096 DPP reductions", launcher<true, false, 4096, false>, false, true, false},
+        {"adler32 V=4096", launcher<true, false, 4096, false>, false, true, false},
+        {"adler32 V=4096+8192 wave priorities", launcher<true, false, 4096 + 8192, false>, false, true, false},
         {"crc32 V=0 (round-1 form)", launcher<false, true, 0, false>, true, false, false},
-        {"crc32 V=194 built, lds barrier, x32 fold", launcher<false, true, 194, false>, true, false, false},
-        {"crc32 V=1218 + byte-addressed image", launcher<false, true, 1218, false>, true, false, false},
-        {"crc32 V=3266 + direct image, one barrier", launcher<false, true, 3266, false>, true, false, false},
-        {"crc32 V=7362 + two-level weights, DPP", launcher<false, true, 7362, false>, true, false, false},
-        {"crc32 V=7362+32 no lane multiply (timing only)", launcher<false, true, 7362 + 32, false>, true, false, false},
-        {"fused V=194", launcher<true, true, 194, false>, true, true, false},
-        {"fused V=3266", launcher<true, true, 3266, false>, true, true, false},
+        {"crc32 V=7362", launcher<false, true, 7362, false>, true, false, false},
+        {"crc32 V=7362+8192 wave priorities", launcher<false, true, 7362 + 8192, false>, true, false, false},
         {"fused V=7362", launcher<true, true, 7362, false>, true, true, false},
-        {"adler32 V=4096 PROFILE", launcher<true, false, 4096, true>, false, true, true},
-        {"crc32 V=3266 PROFILE", launcher<false, true, 3266, true>, true, false, true},
-        {"crc32 V=7362 PROFILE", launcher<false, true, 7362, true>, true, false, true},
+        {"fused V=7362+8192 wave priorities", launcher<true, true, 7362 + 8192, false>, true, true, false},
+        {"fused V=7362 PROFILE", launcher<true, true, 7362, true>, true, true, true},
+        {"fused V=7362+8192 PROFILE", launcher<true, true, 7362 + 8192, true>, true, true, true},
     };
 
     const int WARM = 300, REPS = 200;

@@ -180,6 +180,7 @@ constexpr int kVarDirectImage = 2048; // every lane computes the eight image ent
                                       //   copy of the stride tables, ONE prologue barrier (needs kVarBuildTables|kVarByteAddr|kVarFoldX32)
 constexpr int kVarTreeEpilogue = 4096; // lane weights in two levels (lane-in-wave from LDS, then wave) instead of 32 loads per lane;
                                       //   DPP wave reductions; the group-weight multiplies spread over the lanes of wave 0
+constexpr int kVarWavePrio    = 8192; // later-launched waves of the workgroup get the higher issue priority (s_setprio wave / 4)
 constexpr int kVarEarlyRows   = 768;  // two bits: how many rows of group 0 are requested BEFORE the table build when
                                       //   kVarBuildTables is on: 0 -> all (4), 256 -> none, 512 -> one, 768 -> two
 // Measured on MI355X (tools/micro/crc_phases.hip, profiles/r02_crc_phases.md), crc32 over 64 MiB, dispatch time:
@@ -209,6 +210,14 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
         }
     };
     stamp(0);
+    if constexpr ((V & kVarWavePrio) != 0) {
+        // the 16 waves of the workgroup start over ~1.1 us and the issue arbiter prefers the oldest: the last wave
+        // finishes the stream well behind the first, and the workgroup is as slow as its last wave
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+        if (wv >= 12) __builtin_amdgcn_s_setprio(3);
+        else if (wv >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+    }
 
     // contiguous run of units for this workgroup
     const long long G = gridDim.x, g = blockIdx.x;
