@@ -346,6 +346,27 @@ typedef struct zng_rocm_inflate_job {
 } zng_rocm_inflate_job;
 int  zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthreads);
 
+/* Many independent raw deflate streams that are ALREADY in device memory, decoded entirely on the device: one wavefront
+ * per stream runs slot `inflate_fast` (inffast_tpl.h:53-318) and the block decoding around it (inflate.c:735-917,
+ * inftrees.c:32-297) -- Huffman decode and copies -- with the last 8 KiB of output in an LDS ring (inflate's sliding
+ * window, inflate.c:325-378).  The inverse of zng_rocm_deflate_quick_dev for the reference's many-stream model
+ * (test/pigz/CMakeLists.txt:123-200): nothing crosses PCIe.  `dict_len` bytes of history (a dictionary,
+ * inflateSetDictionary on a raw stream inflate.c:1214-1261, or the previous window) must sit directly in front of `out`.
+ * Asynchronous on `stream`; jobs is a host array (copied before the call returns).
+ * d_results: 4 uint32 per job: {bytes produced, input bytes consumed, status as int32 (1 = Z_STREAM_END, -3 = Z_DATA_ERROR,
+ * -5 = Z_BUF_ERROR: input ended early or out_cap too small), message id for zng_rocm_inflate_message}. */
+typedef struct zng_rocm_inflate_dev_job {
+    const void *in;        /* device: raw deflate stream */
+    void       *out;       /* device: plaintext */
+    uint64_t    in_len;    /* < 2 GiB */
+    uint64_t    out_cap;   /* < 2 GiB */
+    uint32_t    dict_len;  /* <= 32768 */
+    uint32_t    flags;     /* 0 */
+} zng_rocm_inflate_dev_job;
+int  zng_rocm_inflate_streams_dev(const zng_rocm_inflate_dev_job *jobs, size_t njobs, uint32_t *d_results, void *stream);
+/* the reference's strm->msg text for a message id of d_results ("" for 0 / unknown ids) */
+const char *zng_rocm_inflate_message(uint32_t id);
+
 /* ONE raw stream with its host decode spread over `nthreads` threads (zng_rocm_inflate_tokens_decode_threads) and one
  * device pass; same results and status as zng_rocm_inflate_raw_window, which it falls back to for streams that
  * offer no block boundary to cut at or turn out irregular.  Synchronous. */

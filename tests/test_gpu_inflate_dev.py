@@ -1,0 +1,188 @@
+"""GPU parity: zng_rocm_inflate_streams_dev -- whole inflate (block headers, table construction, Huffman decode, copies)
+on the device, one wavefront per stream, for many device-resident raw streams.
+
+Checked against: the plaintext (streams from CPython's zlib, an independent RFC 1951 encoder, at levels 0/1/6/9 and
+with the Z_FIXED / Z_HUFFMAN_ONLY / Z_RLE strategies, with and without a dictionary); the oracle inflater for status and
+strm->msg on the reference's infcover streams (tests/golden/inflate_kat.json, from test/infcover.c); the reference's own
+fixtures (tests/golden/ref_fixtures); the product's level-1 class encoder at BASELINE.json configs[4] size."""
+import importlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import inflate_util
+import ref_fixtures
+import synth
+from gpu_common import product, torch_mod
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "inflate_kat.json")))
+
+
+@pytest.fixture(scope="module")
+def inf():
+    zr = product()
+    zr.init()
+    return importlib.import_module("zlib-ng_amd.inflate")
+
+
+def _raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, zdict=None):
+    if zdict is None:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    else:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy, zdict)
+    return c.compress(data) + c.flush()
+
+
+def _run(inf, streams, caps, dicts=None, pad_in=0):
+    """lay the streams out (each at an odd offset: the kernel must not assume alignment), decode, return rows + outputs"""
+    torch = torch_mod()
+    in_off, pos = [], 1 + pad_in
+    for s in streams:
+        in_off.append(pos)
+        pos += len(s) + 3
+    src = np.zeros(pos + 64, dtype=np.uint8)
+    for o, s in zip(in_off, streams):
+        src[o:o + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+    out_off, pos = [], 5
+    dl = [0] * len(streams) if dicts is None else [len(d) for d in dicts]
+    for c, d in zip(caps, dl):
+        pos += d
+        out_off.append(pos)
+        pos += c + 7
+    dst_host = np.full(pos + 64, 0xA5, dtype=np.uint8)
+    if dicts is not None:
+        for o, d in zip(out_off, dicts):
+            if len(d):
+                dst_host[o - len(d):o] = np.frombuffer(bytes(d), dtype=np.uint8)
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.from_numpy(dst_host).cuda()
+    b = inf.InflateDevBatch(d_src, in_off, [len(s) for s in streams], d_dst, out_off, caps, dl)
+    b.run()
+    rows = b.rows()
+    got = d_dst.cpu().numpy()
+    outs = [got[o:o + r[1]].tobytes() for o, r in zip(out_off, rows)]
+    # nothing outside [out_off, out_off + cap) may have been touched
+    for o, c, d in zip(out_off, caps, dl):
+        assert got[o + c:o + c + 7].tolist() == [0xA5] * 7
+        assert (got[o - d - 5:o - d] == 0xA5).all() or o - d - 5 < 0
+    return rows, outs
+
+
+def test_corpus_levels_and_strategies(inf):
+    rng = np.random.default_rng(3)
+    cases = {
+        "mix": synth.silesia_like(1 << 20, seed=7, seg_bytes=256 << 10).tobytes(),
+        "zeros": b"\0" * 300000,
+        "period7": b"abcdefg" * 20000,
+        "period300": bytes(rng.integers(0, 256, size=300, dtype=np.uint8)) * 900,
+        "random": rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes(),
+        "empty": b"",
+        "one": b"x",
+        "far": rng.integers(0, 256, size=32768, dtype=np.uint8).tobytes() * 5,     # distance 32768 everywhere
+        "text": (b"the quick brown fox jumps over the lazy dog; " * 3000)[:100001],
+    }
+    streams, plains, names = [], [], []
+    for name, data in cases.items():
+        for level, strat in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                             (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            streams.append(_raw(data, level, strat))
+            plains.append(data)
+            names.append((name, level, strat))
+    rows, outs = _run(inf, streams, [len(p) for p in plains])
+    for nm, s, p, r, o in zip(names, streams, plains, rows, outs):
+        assert r == (1, len(p), len(s), ""), (nm, r)
+        assert o == p, nm
+
+
+def test_infcover_streams_status_and_message(inf):
+    streams = [bytes(int(t, 16) for t in r["hex"].split()) for r in KAT["rows"]]
+    rows, outs = _run(inf, streams, [70000] * len(streams))
+    for src, r, o in zip(streams, rows, outs):
+        ost, omsg, oout, _ = inflate_util.oracle_inflate(src, cap=70000)
+        assert (r[0], r[3]) == (ost, omsg), (src.hex(), r)
+        if ost == 1:
+            assert o == oout and r[1] == len(oout)
+
+
+def test_dictionary_and_window(inf):
+    rng = np.random.default_rng(11)
+    dic = (b"dictionary words: alpha beta gamma delta epsilon " * 400)[:20000]
+    data = dic[5000:9000] + b" and fresh text " + dic[100:3000] + bytes(rng.integers(97, 123, size=5000, dtype=np.uint8))
+    s = _raw(data, 9, zdict=dic)
+    # previous-window form: second half of a longer stream decoded with the first half's tail as history
+    whole = synth.silesia_like(400000, seed=3).tobytes()
+    first, second = whole[:200000], whole[200000:]
+    s2 = _raw(second, 6, zdict=first[-32768:])
+    rows, outs = _run(inf, [s, s2], [len(data), len(second)], dicts=[dic, first[-32768:]])
+    assert rows[0] == (1, len(data), len(s), "") and outs[0] == data
+    assert rows[1] == (1, len(second), len(s2), "") and outs[1] == second
+    # without the history the same stream must fail the way the reference does
+    rows, _ = _run(inf, [s], [len(data)])
+    assert rows[0][0] == -3 and rows[0][3] == "invalid distance too far back"
+
+
+def test_truncated_input_and_small_output(inf):
+    data = synth.silesia_like(200000, seed=5).tobytes()
+    s = _raw(data, 6)
+    cuts = [0, 1, 2, 5, len(s) // 3, len(s) - 1]
+    rows, _ = _run(inf, [s[:c] for c in cuts] + [s, s], [len(data)] * len(cuts) + [len(data) - 1, 1000])
+    for c, r in zip(cuts, rows):
+        assert r[0] == -5 and r[3] == "input ended before the final block", (c, r)
+    assert rows[len(cuts)][0] == -5 and rows[len(cuts)][3] == "output buffer too small"
+    assert rows[len(cuts) + 1][0] == -5 and rows[len(cuts) + 1][1] <= 1000
+    # trailing bytes behind the final block are not consumed
+    rows, outs = _run(inf, [s + b"trailing garbage"], [len(data)])
+    assert rows[0] == (1, len(data), len(s), "") and outs[0] == data
+
+
+def test_reference_fixtures(inf):
+    """the raw deflate payload of every .gz the reference holds (test/CVE-*, test/GH-*): same status as the oracle
+    inflater, same bytes when it succeeds; the plain corpora through CPython's encoder and back"""
+    streams, expect = [], []
+    for entry, data in ref_fixtures.compressed():
+        if entry["format"] == "gzip":
+            pos, _ = ref_fixtures.gzip_payload(data)
+            raw = data[pos:]                           # the trailer stays behind the stream: it must not be consumed
+        else:
+            raw = data[2:]                             # zlib wrapper: CMF, FLG
+        streams.append(raw)
+        expect.append(inflate_util.oracle_inflate(raw, cap=4 << 20))
+    for entry, p in ref_fixtures.plain():
+        streams.append(_raw(p, 6))
+        expect.append((1, "", p, None))
+    rows, outs = _run(inf, streams, [max(len(x[2]), 1) + 100 if x[0] == 1 else 4 << 20 for x in expect])
+    assert len(streams) >= 8
+    for r, o, x in zip(rows, outs, expect):
+        assert r[0] == x[0] and r[3] == x[1], (r, x[0], x[1])
+        if x[0] == 1:
+            assert o == x[2]
+
+
+def test_round_trip_of_the_level1_class_at_cfg5_size(inf):
+    """BASELINE.json configs[4]: 4096 x 1 MiB through zng_rocm_deflate_quick_dev, then back through
+    zng_rocm_inflate_streams_dev, everything device resident; every stream compared on the device"""
+    torch = torch_mod()
+    dfl = importlib.import_module("zlib-ng_amd.deflate")
+    n, per = 4096, 1 << 20
+    base = torch.from_numpy(synth.silesia_like(64 << 20, seed=21)).cuda()
+    src = base.repeat(n * per // base.numel())
+    # make the streams different from one another
+    src.view(n, per)[:, :8] = torch.arange(n, device="cuda", dtype=torch.int64).view(n, 1).expand(n, 8).to(torch.uint8)
+    q = dfl.QuickBatch(src, [i * per for i in range(n)], [per] * n)
+    q.run()
+    res = q.results.cpu()
+    clen = [int(res[i, 0]) for i in range(n)]
+    dst = torch.full((n * per + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    b = inf.InflateDevBatch(q.dst, q.out_off, clen, dst, [i * per for i in range(n)], [per] * n)
+    b.run()
+    torch.cuda.synchronize()
+    r = b.results.cpu()
+    assert (r[:, 2] == 1).all() and (r[:, 0] == per).all() and (r[:, 3] == 0).all()
+    assert r[:, 1].tolist() == clen
+    assert torch.equal(dst[:n * per], src)
+    assert (dst[n * per:] == 0x5A).all()

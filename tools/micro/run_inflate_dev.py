@@ -1,0 +1,56 @@
+"""timing / profiling target: zng_rocm_inflate_streams_dev on N x 1 MiB streams.
+  python tools/micro/run_inflate_dev.py [nstreams] [encoder: quick | zlib1 | zlib6 | zlib9] [reps]
+quick  = the product's level-1 class (one static-Huffman block per stream), compressed on the device;
+zlibL  = CPython zlib level L (dynamic blocks) of 64 distinct MiB, repeated to N streams."""
+import importlib, os, sys, time, zlib
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+import numpy as np
+import torch, synth
+zr = importlib.import_module("zlib-ng_amd"); dfl = importlib.import_module("zlib-ng_amd.deflate")
+inf = importlib.import_module("zlib-ng_amd.inflate"); zr.init(0)
+ns = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+enc = sys.argv[2] if len(sys.argv) > 2 else "quick"
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+sz = 1 << 20
+distinct = min(ns, 64)
+plain = synth.silesia_like(distinct * sz, seed=0x5EED0005)
+src = torch.from_numpy(plain).cuda().repeat(ns // distinct)
+if enc == "quick":
+    qb = dfl.QuickBatch(src, [i * sz for i in range(ns)], [sz] * ns)
+    qb.run()
+    clen = [int(v) for v in qb.results.cpu()[:, 0]]
+    comp, in_off = qb.dst, qb.out_off
+else:
+    level = int(enc[4:])
+    blobs = []
+    for i in range(distinct):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        blobs.append(c.compress(plain[i * sz:(i + 1) * sz].tobytes()) + c.flush())
+    blobs = blobs * (ns // distinct)
+    clen = [len(b) for b in blobs]
+    in_off, pos = [], 0
+    for b in blobs:
+        in_off.append(pos)
+        pos += (len(b) + 15) & ~15
+    host = np.zeros(pos + 16, dtype=np.uint8)
+    for o, b in zip(in_off, blobs):
+        host[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    comp = torch.from_numpy(host).cuda()
+dst = torch.empty(ns * sz + 64, dtype=torch.uint8, device="cuda")
+b = inf.InflateDevBatch(comp, in_off, clen, dst, [i * sz for i in range(ns)], [sz] * ns)
+b.run()
+torch.cuda.synchronize()
+r = b.results.cpu()
+assert (r[:, 2] == 1).all() and (r[:, 0] == sz).all(), r[:4]
+assert torch.equal(dst[:ns * sz], src)
+zr.trace_begin(reps)
+t0 = time.perf_counter()
+for _ in range(reps):
+    b.run()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / reps
+ms = zr.trace_end(reps)
+k = sum(ms) / len(ms)
+print("%s: %d x 1 MiB, compressed %.1f MiB (ratio %.3f): kernel %.3f ms = %.1f GB/s out, %.1f GB/s in (wall %.3f ms)" %
+      (enc, ns, sum(clen) / 2**20, ns * sz / sum(clen), k, ns * sz / 1e9 / (k / 1e3), sum(clen) / 1e9 / (k / 1e3), wall * 1e3))

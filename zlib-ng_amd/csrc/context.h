@@ -61,6 +61,8 @@ enum ScratchSlot {
     kScrChunkList,          // device: work list of zng_rocm_chunkmemset_safe_dev (long / memmove-order copies)
     kScrInflate,            // device: tokens | segs | literals | symbols of the one-shot inflate
     kScrInflateHost,        // pinned token staging of the batched inflate
+    kScrInflateDevJobs,     // device: InflateJobDev[] of zng_rocm_inflate_streams_dev
+    kScrInflateDevJobsHost, // pinned
     kScrCount
 };
 

@@ -1,0 +1,595 @@
+// inflate_dev.hip -- slot `inflate_fast` (inffast_tpl.h:53-318) together with the block decoding around it
+// (inflate.c:735-917: stored / fixed / dynamic block headers, inftrees.c:32-297 table construction) as ONE device
+// kernel for MANY independent raw deflate streams that are already in device memory -- the shape of the reference's
+// many-stream model (test/pigz/CMakeLists.txt:123-200) on the decode side, and the inverse of
+// zng_rocm_deflate_quick_dev: compress on the device, decompress on the device, nothing crosses PCIe.
+//
+// One wavefront per stream.  A deflate stream is a serial bit parse, so the parse itself is wave-UNIFORM work: the
+// bit buffer, the table entry, the position all live in scalar registers (every lane would compute the same), and the
+// 64 lanes are used where the stream offers width:
+//   * the compressed words are fetched 64 at a time (one dword per lane, the next 64 prefetched) and handed to the
+//     bit buffer with v_readlane -- the parse never waits on a memory load;
+//   * Huffman tables are built lane-parallel (counting sort by ballots, one table entry per lane per pass);
+//   * a match copy moves up to 64 bytes per pass, a stored block 1 KiB per pass;
+//   * the last kRing output bytes live in an LDS ring (the device form of inflate's sliding window, inflate.c:325-378):
+//     literals and near matches never touch HBM, the ring leaves in aligned 16-byte stores, and only a match that
+//     reaches further back than the ring reads its source from HBM (the stream's own earlier output, or the
+//     dictionary / previous window that precedes `out`).
+// Single streams (cfg3) stay with the host-decoded token path (inflate_host.cpp + inflate_resolve.hip), whose host
+// side scales with threads; this kernel scales with the NUMBER of streams.
+//
+// Status and messages are the reference's (inflate.c strm->msg texts, via zng_rocm_inflate_message).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "context.h"
+#include "deflate_dev.h"
+
+namespace zr {
+
+struct InflateJobDev {
+    const uint8_t *in;
+    uint8_t       *out;
+    uint64_t       in_len;
+    uint64_t       out_cap;
+    uint32_t       dict_len;
+    uint32_t       flags;
+};
+
+enum InflateMsg : uint32_t {
+    kMsgNone = 0, kMsgBlockType, kMsgStoredLen, kMsgTooMany, kMsgCodeLengthsSet, kMsgBitRepeat, kMsgNoEob,
+    kMsgLitLenSet, kMsgDistSet, kMsgLitLenCode, kMsgDistCode, kMsgTooFar, kMsgStarved, kMsgOutFull, kMsgCount
+};
+
+// Table entry, 16 bits: code length in bits 0-3, SYMBOL in bits 4-15 (literal/length 0..287, distance 0..31, code-length
+// symbol 0..18).  Base values and extra-bit counts are arithmetic in the symbol (length_of / distance_of), so nothing
+// wider is needed: the three tables of a stream take 3.3 KiB of LDS, and LDS per wave is what bounds how many streams
+// a CU decodes at once.  kLongMark: the code is longer than the table's root; kBadMark: no code has this prefix.
+constexpr uint32_t kLongMark = (0xfffu << 4), kBadMark = (0xffeu << 4) | 1u;
+__device__ __forceinline__ uint32_t make_entry(uint32_t nbits, uint32_t sym) { return nbits | (sym << 4); }
+
+constexpr int kLitRoot = 10, kDistRoot = 9, kClRoot = 7;
+// order in which the code-length code's lengths are sent (RFC 1951 3.2.7; inflate.c:832-833 holds the same permutation)
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+constexpr int kCodeLit = 0, kCodeDist = 1, kCodeCl = 2;
+
+template <int RING>
+struct InflateLds {
+    uint16_t lit[1 << kLitRoot];
+    uint16_t dist[1 << kDistRoot];
+    uint16_t cl[1 << kClRoot];
+    uint32_t cnt[3][16], first[3][16], offs[3][16], run[16];
+    uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[32];
+    uint8_t  lens[320 + 8];
+    uint8_t  cl_lens[24];
+    uint8_t  ring[RING] __attribute__((aligned(16)));
+};
+
+// base values / extra bits of the length and distance symbols (RFC 1951 3.2.5; inftrees.c:38-49 hold the same numbers)
+__device__ __forceinline__ void length_of(uint32_t k, uint32_t *base, uint32_t *extra) {     // k = symbol - 257, 0..28
+    if (k < 8) { *base = 3 + k; *extra = 0; }
+    else if (k == 28) { *base = 258; *extra = 0; }
+    else { const uint32_t e = (k - 4) >> 2; *extra = e; *base = 3 + ((4 + (k & 3)) << e); }
+}
+__device__ __forceinline__ void distance_of(uint32_t k, uint32_t *base, uint32_t *extra) {   // k = symbol, 0..29
+    if (k < 4) { *base = 1 + k; *extra = 0; }
+    else { const uint32_t e = (k - 2) >> 1; *extra = e; *base = 1 + ((2 + (k & 1)) << e); }
+}
+
+__device__ __forceinline__ void wave_sync() {            // LDS written by some lanes is read by others of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Canonical code from `n` code lengths (inftrees.c:32-297 re-thought for a wavefront): per-length counts, the
+// over-subscribed / incomplete checks of inftrees.c:104-137, symbols sorted by (length, symbol), and the root-bit
+// primary table, one entry per lane per pass, each found by the canonical comparison "code - first[L] < count[L]".
+// Codes longer than the root get a kLong entry; the decode loop resolves those with the same comparison (they are the
+// rare symbols by construction).  Returns 0, or 1 for an invalid set.
+template <int RING>
+__device__ int build_code(InflateLds<RING> &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
+                          uint16_t *sorted, int lane) {
+    uint32_t *cnt = L.cnt[which], *first = L.first[which], *offs = L.offs[which];
+    if (lane < 16) cnt[lane] = 0;
+    wave_sync();
+    for (int s = lane; s < n; s += 64) atomicAdd(&cnt[lens[s]], 1u);
+    wave_sync();
+    const uint32_t mine = lane < 16 ? cnt[lane] : 0u;
+    int left = 1, max = 0;
+    uint32_t code = 0, off = 0;
+    bool over = false;
+    for (int len = 1; len <= 15; ++len) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, len);
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+        if (lane == 0) {
+            first[len] = code;
+            offs[len] = off;
+            L.run[len] = off;
+        }
+        code = (code + c) << 1;
+        off += c;
+        if (c) max = len;
+    }
+    if (over) return 1;                                              // over-subscribed (inftrees.c:128-132)
+    if (max == 0) {                                                  // no codes at all (inftrees.c:114-122): every entry invalid
+        for (int e = lane; e < (1 << root); e += 64) table[e] = (uint16_t)(which == kCodeCl ? make_entry(1, 0) : kBadMark);
+        if (lane == 0) cnt[0] = 0;
+        wave_sync();
+        return 0;
+    }
+    if (left > 0 && (which == kCodeCl || max != 1)) return 1;        // incomplete set (inftrees.c:133-134)
+    wave_sync();
+    // stable counting sort: rank of a symbol among the symbols of its length = lower lanes of the same ballot
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t l = s < n ? lens[s] : 0u;
+        bool active = l != 0;
+        unsigned long long m = __ballot(active);
+        while (m) {
+            const int f = __builtin_ctzll(m);
+            const uint32_t lu = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
+            const bool hit = active && l == lu;
+            const unsigned long long same = __ballot(hit);
+            const uint32_t at = uni(L.run[lu]);
+            if (hit) sorted[at + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull))] = (uint16_t)s;
+            if (lane == f) L.run[lu] = at + (uint32_t)__builtin_popcountll(same);
+            active = active && !hit;
+            m &= ~same;
+            wave_sync();
+        }
+    }
+    wave_sync();
+    const int top = max < root ? max : root;
+    for (int e = lane; e < (1 << root); e += 64) {
+        const uint32_t rev = __builtin_bitreverse32((uint32_t)e) >> (32 - root);      // the root bits as a code prefix
+        uint32_t ent = max > root ? kLongMark : kBadMark;
+        for (int len = 1; len <= top; ++len) {
+            const uint32_t d = (rev >> (root - len)) - first[len];
+            if (d < cnt[len]) {
+                ent = make_entry((uint32_t)len, sorted[offs[len] + d]);
+                break;
+            }
+        }
+        table[e] = (uint16_t)ent;
+    }
+    if (lane == 0) cnt[0] = (uint32_t)max;                           // slot 0 is unused by the comparison: keep max there
+    wave_sync();
+    return 0;
+}
+
+// A code longer than the root: the canonical comparison over the remaining lengths, wave-uniform.
+template <int RING>
+__device__ __forceinline__ uint32_t long_code(InflateLds<RING> &L, int which, int root, const uint16_t *sorted,
+                                              unsigned long long hold) {
+    const uint32_t rev15 = __builtin_bitreverse32((uint32_t)hold & 0x7fffu) >> 17;
+    const int max = (int)uni(L.cnt[which][0]);
+    for (int len = root + 1; len <= max; ++len) {
+        const uint32_t d = (rev15 >> (15 - len)) - uni(L.first[which][len]);
+        if (d < uni(L.cnt[which][len])) return make_entry((uint32_t)len, uni(sorted[uni(L.offs[which][len]) + d]));
+    }
+    return kBadMark;
+}
+
+template <int RING>
+__global__ __launch_bounds__(64)
+void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njobs, uint32_t *__restrict__ results) {
+    constexpr uint32_t M = RING - 1;
+    constexpr uint32_t kFlushAt = RING / 2;              // unflushed bytes that trigger a flush
+    constexpr uint32_t kNear = RING - 258;               // a source this close is still in the ring while the match is written
+    // bytes not yet flushed never exceed kFlushAt + 16 + max(258, 1024); a match of 258 more must not overwrite them
+    static_assert(kFlushAt + 16 + 1024 + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
+    __shared__ InflateLds<RING> L;
+    const int lane = threadIdx.x;
+    const uint32_t job = blockIdx.x;
+    if (job >= njobs) return;
+    const InflateJobDev J = jobs[job];
+    const ZR_GLOBAL uint8_t *const in = (const ZR_GLOBAL uint8_t *)J.in;
+    ZR_GLOBAL uint8_t *const out = (ZR_GLOBAL uint8_t *)J.out;
+    const uint32_t in_len = (uint32_t)J.in_len, out_cap = (uint32_t)J.out_cap, dict_len = J.dict_len;
+    const uint32_t a0 = (uint32_t)((uintptr_t)J.out & 15u);            // ring slot of position p is (p + a0) & M
+
+    // ---- compressed words: 64 per fetch, the next 64 prefetched -------------------------------------------------
+    const uint32_t lead = (uint32_t)((uintptr_t)J.in & 3u);
+    const ZR_GLOBAL uint32_t *const words = (const ZR_GLOBAL uint32_t *)(in - lead);
+    const uint32_t total_words = (lead + in_len + 3u) >> 2;
+    auto fetch = [&](uint32_t base) -> uint32_t {
+        const uint32_t k = base + (uint32_t)lane;
+        return k < total_words ? words[k] : 0u;
+    };
+    uint32_t cbase = 0, cur = 0, nxt = 0;
+    uint32_t wnext = 0;                                  // index of the next word to enter the bit buffer
+    unsigned long long hold = 0;
+    uint32_t cnt = 0;
+    auto append = [&]() {                                // cnt <= 32 on entry
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wnext - cbase));
+        hold |= (unsigned long long)w << cnt;
+        cnt += 32;
+        ++wnext;
+        if (wnext - cbase == 64) {
+            cbase += 64;
+            cur = nxt;
+            nxt = fetch(cbase + 64);
+        }
+    };
+    auto seek = [&](uint32_t byte_off) {                 // restart the bit buffer at a byte of the stream
+        const uint32_t a = lead + byte_off;
+        wnext = a >> 2;
+        cbase = wnext;
+        cur = fetch(cbase);
+        nxt = fetch(cbase + 64);
+        hold = 0;
+        cnt = 0;
+        append();
+        hold >>= 8 * (a & 3u);
+        cnt -= 8 * (a & 3u);
+    };
+    auto bit_pos = [&]() -> unsigned long long {         // stream bits consumed so far
+        return 32ull * wnext - 8ull * lead - cnt;
+    };
+    seek(0);
+
+    uint32_t op = 0, flushed = 0;
+    uint32_t msg = kMsgNone;
+    // A run of literals waits in ONE vector register, literal j in lane j (a compare and a select per literal,
+    // no LDS access, no EXEC juggling); the run goes to the ring in one ds_write when a match, a flush or the 64th
+    // literal comes.  `op` already counts the waiting literals.
+    uint32_t litbuf = 0, npend = 0;
+    auto dump = [&]() {
+        if (npend) {
+            if ((uint32_t)lane < npend) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
+            npend = 0;
+        }
+    };
+    // ring -> HBM: everything below `limit` (all of it when `final`), in aligned 16-byte stores
+    auto flush = [&](uint32_t limit, bool final) {
+        if (((a0 + flushed) & 15u) && flushed < limit) {
+            uint32_t h = 16u - ((a0 + flushed) & 15u);
+            if (h > limit - flushed) h = limit - flushed;
+            if ((uint32_t)lane < h) out[flushed + lane] = L.ring[(a0 + flushed + lane) & M];
+            flushed += h;
+        }
+        const uint32_t chunks = (limit - flushed) >> 4;
+        for (uint32_t c = (uint32_t)lane; c < chunks; c += 64) {
+            const uint32_t p = flushed + 16u * c;
+            *(ZR_GLOBAL u32x4_v *)(out + p) = *reinterpret_cast<const u32x4_v *>(&L.ring[(a0 + p) & M]);
+        }
+        flushed += 16u * chunks;
+        if (final && flushed < limit) {
+            if ((uint32_t)lane < limit - flushed) out[flushed + lane] = L.ring[(a0 + flushed + lane) & M];
+            flushed = limit;
+        }
+        // a later far match may read these bytes back from HBM: have the stores acknowledged first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0);
+    };
+    // Everything that is not decoding happens when the literal run is written out, i.e. once per match or per 64
+    // literals: the run goes to the ring (clipped at out_cap: a run may have decoded past it), a flush when one is due,
+    // and the test that ends the decode of a truncated stream (the zero bits behind the input decode to something for ever).
+    auto service = [&]() {
+        if (op > out_cap) {
+            const uint32_t fit = npend - (op - out_cap);
+            if ((uint32_t)lane < fit) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
+            op = out_cap;
+            npend = 0;
+            msg = kMsgOutFull;
+            return;
+        }
+        dump();
+        if (wnext > total_words + 2u) msg = kMsgStarved;     // whole words past the end of the input are in the bit buffer
+        if (op - flushed >= kFlushAt) {
+            wave_sync();
+            flush(op, false);
+        }
+    };
+
+    // The control flow below is kept to single-exit loops with an error word (no jumps out of nested loops): every branch
+    // here is wave-uniform, and anything else makes the compiler carry loop-exit conditions as lane masks through the
+    // hot loop (the first version of this kernel executed 73 scalar instructions per symbol, most of them that).
+    bool last = false;
+    while (!last && msg == kMsgNone) {
+        if (cnt < 32) append();
+        last = hold & 1u;
+        const uint32_t type = (uint32_t)(hold >> 1) & 3u;
+        hold >>= 3;
+        cnt -= 3;
+        if (type == 3) { msg = kMsgBlockType; break; }
+        if (type == 0) {
+            // stored block (inflate.c:759-800): LEN / NLEN at the next byte boundary, then LEN raw bytes
+            service();
+            if (msg != kMsgNone) break;
+            wave_sync();
+            hold >>= cnt & 7u;
+            cnt -= cnt & 7u;
+            if (cnt < 32) append();
+            const uint32_t len = (uint32_t)hold & 0xffffu, nlen = (uint32_t)(hold >> 16) & 0xffffu;
+            hold >>= 32;
+            cnt -= 32;
+            if (bit_pos() > 8ull * in_len) { msg = kMsgStarved; break; }
+            if (len != (nlen ^ 0xffffu)) { msg = kMsgStoredLen; break; }
+            const uint32_t from = (uint32_t)(bit_pos() >> 3);          // byte aligned here
+            const uint32_t avail = in_len - from;
+            uint32_t n = len < avail ? len : avail;
+            if (n > out_cap - op) n = out_cap - op;
+            for (uint32_t done_n = 0; done_n < n;) {
+                if (op - flushed >= kFlushAt) flush(op, false);
+                const uint32_t piece = n - done_n < 1024u ? n - done_n : 1024u;
+                const uint32_t lo = 16u * (uint32_t)lane;
+                if (lo < piece) {
+                    const ZR_GLOBAL uint8_t *src = in + from + done_n + lo;
+                    if (lo + 16u <= piece) {
+                        const u32x4_unaligned v = *(const ZR_GLOBAL u32x4_unaligned *)src;
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) L.ring[(a0 + op + lo + k) & M] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                    } else {
+                        for (uint32_t k = 0; lo + k < piece; ++k) L.ring[(a0 + op + lo + k) & M] = src[k];
+                    }
+                }
+                op += piece;
+                done_n += piece;
+                wave_sync();
+            }
+            if (len > avail) { msg = kMsgStarved; break; }
+            if (n < len) { msg = kMsgOutFull; break; }
+            seek(from + len);
+            continue;
+        }
+        if (type == 1) {
+            // fixed codes (RFC 1951 3.2.6, inflate.c:801-813): the same builder, from the fixed lengths
+            for (int s = lane; s < 288; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) L.lens[288 + lane] = 5;
+            wave_sync();
+            build_code(L, kCodeLit, L.lens, 288, kLitRoot, L.lit, L.sorted_lit, lane);
+            build_code(L, kCodeDist, L.lens + 288, 32, kDistRoot, L.dist, L.sorted_dist, lane);
+        } else {
+            // dynamic block header (inflate.c:814-917)
+            if (cnt < 32) append();
+            const uint32_t nlen = ((uint32_t)hold & 31u) + 257u, ndist = ((uint32_t)(hold >> 5) & 31u) + 1u,
+                           ncode = ((uint32_t)(hold >> 10) & 15u) + 4u;
+            hold >>= 14;
+            cnt -= 14;
+            if (nlen > 286 || ndist > 30) { msg = kMsgTooMany; break; }
+            if (lane < 19) L.cl_lens[lane] = 0;
+            wave_sync();
+            for (uint32_t i = 0; i < ncode; ++i) {
+                if (cnt < 32) append();
+                if (lane == 0) L.cl_lens[kClOrder[i]] = (uint8_t)(hold & 7u);
+                hold >>= 3;
+                cnt -= 3;
+            }
+            wave_sync();
+            if (uni((uint32_t)build_code(L, kCodeCl, L.cl_lens, 19, kClRoot, L.cl, L.sorted_cl, lane))) { msg = kMsgCodeLengthsSet; break; }
+            uint32_t have = 0;
+            while (have < nlen + ndist) {
+                if (cnt < 32) append();
+                const uint32_t e = uni(L.cl[(uint32_t)hold & ((1u << kClRoot) - 1u)]);
+                // an empty code-length code yields one-bit entries of value 0: each reads as length 0
+                // (inftrees.c:114-122 + inflate.c:846-849)
+                const uint32_t nb = e & 15u, sym = e >> 4;
+                hold >>= nb;
+                cnt -= nb;
+                if (sym < 16) {
+                    if (lane == 0) L.lens[have] = (uint8_t)sym;
+                    ++have;
+                    continue;
+                }
+                uint32_t rep, val = 0;
+                if (sym == 16) {
+                    if (have == 0) { msg = kMsgBitRepeat; break; }
+                    wave_sync();
+                    val = uni(L.lens[have - 1]);
+                    rep = 3u + ((uint32_t)hold & 3u);
+                    hold >>= 2;
+                    cnt -= 2;
+                } else if (sym == 17) {
+                    rep = 3u + ((uint32_t)hold & 7u);
+                    hold >>= 3;
+                    cnt -= 3;
+                } else {
+                    rep = 11u + ((uint32_t)hold & 127u);
+                    hold >>= 7;
+                    cnt -= 7;
+                }
+                if (have + rep > nlen + ndist) { msg = kMsgBitRepeat; break; }
+                for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L.lens[have + k] = (uint8_t)val;
+                have += rep;
+            }
+            if (msg != kMsgNone) break;
+            wave_sync();
+            if (bit_pos() > 8ull * in_len) { msg = kMsgStarved; break; }
+            if (uni(L.lens[256]) == 0) { msg = kMsgNoEob; break; }
+            if (uni((uint32_t)build_code(L, kCodeLit, L.lens, (int)nlen, kLitRoot, L.lit, L.sorted_lit, lane))) { msg = kMsgLitLenSet; break; }
+            if (uni((uint32_t)build_code(L, kCodeDist, L.lens + nlen, (int)ndist, kDistRoot, L.dist, L.sorted_dist, lane))) {
+                msg = kMsgDistSet;
+                break;
+            }
+        }
+
+        // ---- symbol loop: the decode AND store halves of inflate_fast (inffast_tpl.h:140-300) -----------------------
+        for (;;) {
+            // literals: the tight loop; it ends at the first symbol that is not a literal
+            uint32_t e;
+            for (;;) {
+                if (cnt < 32) append();
+                e = uni(L.lit[(uint32_t)hold & ((1u << kLitRoot) - 1u)]);
+                if (e >= (256u << 4)) break;
+                const uint32_t nb = e & 15u;
+                hold >>= nb;
+                cnt -= nb;
+                litbuf = (uint32_t)lane == npend ? (e >> 4) : litbuf;
+                ++npend;
+                ++op;
+                if (npend == 64) {
+                    service();
+                    if (msg != kMsgNone) break;
+                }
+            }
+            if (msg != kMsgNone) break;
+            if (e == kLongMark) {
+                e = long_code(L, kCodeLit, kLitRoot, L.sorted_lit, hold);
+                if (e < (256u << 4)) {                                                // a literal with a long code
+                    const uint32_t nb = e & 15u;
+                    hold >>= nb;
+                    cnt -= nb;
+                    litbuf = (uint32_t)lane == npend ? (e >> 4) : litbuf;
+                    ++npend;
+                    ++op;
+                    if (npend == 64) {
+                        service();
+                        if (msg != kMsgNone) break;
+                    }
+                    continue;
+                }
+            }
+            const uint32_t sym = e >> 4, nb = e & 15u;
+            if (sym > 285u) { msg = kMsgLitLenCode; break; }                          // 286, 287 (inftrees.c:44-45), no code
+            hold >>= nb;
+            cnt -= nb;
+            if (sym == 256u) break;                                                   // end of block
+            // length: base and extra bits from the symbol (RFC 1951 3.2.5; inftrees.c:38-45 tabulate the same)
+            const uint32_t k = sym - 257u;
+            uint32_t len;
+            if (k < 8u) {
+                len = 3u + k;
+            } else if (k == 28u) {
+                len = 258u;
+            } else {
+                const uint32_t xb = (k - 4u) >> 2;
+                len = 3u + ((4u + (k & 3u)) << xb) + ((uint32_t)hold & ((1u << xb) - 1u));
+                hold >>= xb;
+                cnt -= xb;
+            }
+            if (cnt < 32) append();
+            uint32_t d = uni(L.dist[(uint32_t)hold & ((1u << kDistRoot) - 1u)]);
+            if (d == kLongMark) d = long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold);
+            const uint32_t dsym = d >> 4, dnb = d & 15u;
+            if (dsym > 29u) { msg = kMsgDistCode; break; }                            // 30, 31 (inftrees.c:48-49), no code
+            hold >>= dnb;
+            cnt -= dnb;
+            uint32_t dist;
+            if (dsym < 4u) {
+                dist = 1u + dsym;
+            } else {
+                const uint32_t xb = (dsym - 2u) >> 1;
+                dist = 1u + ((2u + (dsym & 1u)) << xb) + ((uint32_t)hold & ((1u << xb) - 1u));
+                hold >>= xb;
+                cnt -= xb;
+            }
+            if (dist > op && dist - op > dict_len) { msg = kMsgTooFar; break; }       // inffast_tpl.h:203-210
+            service();
+            if (msg != kMsgNone) break;
+            if (len > out_cap - op) { msg = kMsgOutFull; break; }
+            wave_sync();                                                              // earlier literals are in the ring
+            const int src0 = (int)op - (int)dist;
+            if (dist <= kNear && dist <= op) {
+                // ring to ring.  Every source byte was produced before this match began (with dist < len the
+                // sources are the `dist` bytes before op, repeated): the passes of the copy are independent.
+                if (dist >= len) {
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64)
+                        L.ring[(a0 + op + i) & M] = L.ring[(a0 + (uint32_t)src0 + i) & M];
+                } else if (dist == 1) {
+                    const uint8_t v = L.ring[(a0 + (uint32_t)src0) & M];
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) L.ring[(a0 + op + i) & M] = v;
+                } else {
+                    const float inv = 1.0f / (float)dist;
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        uint32_t q = (uint32_t)((float)i * inv);
+                        int r = (int)i - (int)(q * dist);
+                        if (r < 0) r += (int)dist;
+                        if (r >= (int)dist) r -= (int)dist;
+                        L.ring[(a0 + op + i) & M] = L.ring[(a0 + (uint32_t)src0 + (uint32_t)r) & M];
+                    }
+                }
+            } else {
+                // a source beyond the ring's reach, or in the history in front of `out`: HBM, except for the bytes
+                // that have not left the ring yet (a match that starts in the dictionary and runs into this stream)
+                const float inv = 1.0f / (float)dist;
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                    uint32_t j = i;
+                    if (dist < len) {
+                        uint32_t q = (uint32_t)((float)i * inv);
+                        int r = (int)i - (int)(q * dist);
+                        if (r < 0) r += (int)dist;
+                        if (r >= (int)dist) r -= (int)dist;
+                        j = (uint32_t)r;
+                    }
+                    const int sp = src0 + (int)j;
+                    const uint8_t v = sp >= (int)flushed ? L.ring[(a0 + (uint32_t)sp) & M] : out[sp];
+                    L.ring[(a0 + op + i) & M] = v;
+                }
+            }
+            op += len;
+        }
+    }
+    // bits that do not exist were consumed: whatever happened after that point, the stream ended early
+    if (msg != kMsgOutFull) service();                   // (an out-of-room exit has clipped the run already)
+    if (bit_pos() > 8ull * in_len) msg = kMsgStarved;
+    wave_sync();
+    flush(op, true);
+    if (lane == 0) {
+        const unsigned long long used = (bit_pos() + 7ull) >> 3;
+        results[4 * job + 0] = op;
+        results[4 * job + 1] = used > in_len ? in_len : (uint32_t)used;
+        results[4 * job + 2] = msg == kMsgNone ? 1u : (msg == kMsgStarved || msg == kMsgOutFull) ? (uint32_t)-5 : (uint32_t)-3;
+        results[4 * job + 3] = msg;
+    }
+}
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+const char *zng_rocm_inflate_message(uint32_t id) {
+    static const char *const text[kMsgCount] = {
+        "", "invalid block type", "invalid stored block lengths", "too many length or distance symbols",
+        "invalid code lengths set", "invalid bit length repeat", "invalid code -- missing end-of-block",
+        "invalid literal/lengths set", "invalid distances set", "invalid literal/length code", "invalid distance code",
+        "invalid distance too far back", "input ended before the final block", "output buffer too small"};
+    return id < kMsgCount ? text[id] : "";
+}
+
+int zng_rocm_inflate_streams_dev(const zng_rocm_inflate_dev_job *jobs, size_t njobs, uint32_t *d_results, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!njobs) return ZNG_ROCM_OK;
+    if (!jobs || !d_results || njobs > 0x7fffffffull) return ZNG_ROCM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dev;
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    InflateJobDev *d_jobs = nullptr, *h_jobs = nullptr;
+    if (int rc = scratch_reserve(ws, kScrInflateDevJobs, njobs * sizeof(InflateJobDev), false, (void **)&d_jobs)) return rc;
+    if (int rc = host_tables_acquire(ws)) return rc;
+    if (int rc = scratch_reserve(ws, kScrInflateDevJobsHost, njobs * sizeof(InflateJobDev), true, (void **)&h_jobs)) return rc;
+    for (size_t i = 0; i < njobs; ++i) {
+        const zng_rocm_inflate_dev_job &j = jobs[i];
+        if ((j.in_len && !j.in) || (j.out_cap && !j.out) || j.in_len > 0x7fffffffull || j.out_cap > 0x7fffffffull ||
+            j.dict_len > 32768u || (j.dict_len && !j.out) || j.flags) {
+            set_error("job %zu: null buffer, a stream or output of 2 GiB and more, dict_len above 32768, or unknown flags", i);
+            return ZNG_ROCM_EINVAL;
+        }
+        h_jobs[i] = InflateJobDev{(const uint8_t *)j.in, (uint8_t *)j.out, j.in_len, j.out_cap, j.dict_len, j.flags};
+    }
+    ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
+    if (int rc = host_tables_release(ws, st)) return rc;
+    int ring = 4096;                 // measured: 4 KiB -> 17 streams per CU; 8 KiB (12 per CU) is 25 % slower on both corpora
+    if (const char *r = getenv("ZNG_ROCM_INFLATE_RING")) ring = atoi(r);
+    if (ring == 8192) ZR_LAUNCH_TRACED(inflate_streams_kernel<8192>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else if (ring == 16384) ZR_LAUNCH_TRACED(inflate_streams_kernel<16384>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else if (ring == 32768) ZR_LAUNCH_TRACED(inflate_streams_kernel<32768>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else ZR_LAUNCH_TRACED(inflate_streams_kernel<4096>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+}  // extern "C"

@@ -156,3 +156,53 @@ def inflate_raw_threads(src, dst, window=None, nthreads=0):
     rc = rocm.lib().zng_rocm_inflate_raw_threads(C.addressof(hs.buf), hs.n, None if not wl else rocm._dev_ptr(window), wl,
                                                  rocm._dev_ptr(dst), dst.numel(), C.byref(produced), C.byref(used), nthreads)
     return rc, produced.value, used.value
+
+
+class InflateDevJob(C.Structure):
+    """zng_rocm_inflate_dev_job"""
+    _fields_ = [("in_ptr", C.c_void_p), ("out_ptr", C.c_void_p), ("in_len", C.c_uint64), ("out_cap", C.c_uint64),
+                ("dict_len", C.c_uint32), ("flags", C.c_uint32)]
+
+
+def inflate_message(msg_id):
+    return (rocm.lib().zng_rocm_inflate_message(int(msg_id)) or b"").decode()
+
+
+class InflateDevBatch:
+    """Many raw deflate streams that already sit in device memory, decoded on the device (zng_rocm_inflate_streams_dev).
+
+    src: uint8 CUDA tensor; stream i = src[in_off[i] : in_off[i] + in_len[i]].
+    dst: uint8 CUDA tensor; stream i's plaintext goes to dst[out_off[i] : out_off[i] + out_cap[i]], with dict_len[i]
+         bytes of history directly in front of out_off[i] (inside dst).
+    results: int32 CUDA tensor [n, 4] = {bytes produced, input bytes used, zlib status, message id}."""
+
+    def __init__(self, src, in_off, in_len, dst, out_off, out_cap, dict_len=None):
+        import torch
+        rocm._need_init()
+        self.src, self.dst = src, dst
+        self.n = len(in_len)
+        self.results = torch.zeros((self.n, 4), dtype=torch.int32, device=src.device)
+        self.jobs = (InflateDevJob * self.n)()
+        bi, bo = src.data_ptr(), dst.data_ptr()
+        for i in range(self.n):
+            d = 0 if dict_len is None else int(dict_len[i])
+            if d > int(out_off[i]):
+                raise ValueError("the history must lie inside dst, in front of the stream's output")
+            if int(in_off[i]) + int(in_len[i]) > src.numel() or int(out_off[i]) + int(out_cap[i]) > dst.numel():
+                raise ValueError("stream %d does not fit its tensor" % i)
+            self.jobs[i].in_ptr = bi + int(in_off[i])
+            self.jobs[i].out_ptr = bo + int(out_off[i])
+            self.jobs[i].in_len = int(in_len[i])
+            self.jobs[i].out_cap = int(out_cap[i])
+            self.jobs[i].dict_len = d
+            self.jobs[i].flags = 0
+
+    def run(self, stream=None):
+        """asynchronous on `stream`"""
+        rocm._check(rocm.lib().zng_rocm_inflate_streams_dev(C.byref(self.jobs), self.n, rocm._dev_ptr(self.results),
+                                                            rocm._stream_ptr(stream)), "zng_rocm_inflate_streams_dev")
+
+    def rows(self):
+        """[(status, out_len, in_used, message)] (synchronises)"""
+        r = self.results.cpu().tolist()
+        return [(row[2], row[0], row[1], inflate_message(row[3])) for row in r]
