@@ -486,7 +486,11 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             if (len > out_cap - op) { msg = kMsgOutFull; break; }
             wave_sync();                                                              // earlier literals are in the ring
             const int src0 = (int)op - (int)dist;
-            if (dist <= kNear && dist <= op) {
+            if (dist <= kNear && dist <= op && dist >= len && len <= 64u) {
+                // the common shape, one pass, no loop: a short match that does not overlap itself, source in the ring
+                if ((uint32_t)lane < len)
+                    L.ring[(a0 + op + (uint32_t)lane) & M] = L.ring[(a0 + (uint32_t)src0 + (uint32_t)lane) & M];
+            } else if (dist <= kNear && dist <= op) {
                 // ring to ring.  Every source byte was produced before this match began (with dist < len the
                 // sources are the `dist` bytes before op, repeated): the passes of the copy are independent.
                 if (dist >= len) {
