@@ -248,6 +248,33 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     for i in ([0, count - 1] if count else []):
         k = (first + i) % distinct
         assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == base[k * each:(k + 1) * each].tobytes()
+    # ... and back, on the device: this rank's compressed streams through zng_rocm_inflate_streams_dev (one wavefront per
+    # stream: block headers, table build, Huffman decode and copies), compared with the plaintext on the device
+    inf = importlib.import_module("zlib-ng_amd.inflate")
+    back_ms, back_kernel_ms = float("nan"), float("nan")
+    if count:
+        plain = torch.empty(count * each + 64, dtype=torch.uint8, device=dev)
+        clens = [int(v) for v in res[:, 0]]
+        ib = inf.InflateDevBatch(batch.dst, batch.out_off, clens, plain, [i * each for i in range(count)], [each] * count)
+        ib.run()
+        fence()
+        reps = 3
+        zr.trace_begin(reps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ib.run()
+        fence()
+        back_ms = (time.perf_counter() - t0) / reps * 1e3
+        km = zr.trace_end(reps)
+        back_kernel_ms = statistics.mean(km) if km else float("nan")
+        rows = ib.results.cpu()
+        assert bool((rows[:, 2] == 1).all()) and bool((rows[:, 0] == each).all()) and rows[:, 1].tolist() == clens
+        assert torch.equal(plain[:count * each], src[:count * each]), "device inflate differs from the plaintext"
+        del plain, ib
+    tb = torch.tensor([back_ms if count else 0.0], dtype=torch.float64, device="cpu" if rehearse else dev)
+    if world > 1:
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+    back_ms = tb.item()
     if rank != 0:
         return None
     total_in = args.streams * each
@@ -270,6 +297,12 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
                      "frac": round(local_bytes / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(k_ms, 3)},
     }
+    out["inflate_back"] = {
+        "workload": "the same %d streams, as compressed above, decoded on the device (zng_rocm_inflate_streams_dev) and "
+                    "compared with the plaintext on the device" % args.streams,
+        "value": round(total_in / 1e9 / (back_ms / 1e3), 2), "unit": "GB/s of output", "ms": round(back_ms, 3),
+        "kernel_ms_rank0": round(back_kernel_ms, 3), "bit_exact": True,
+        "reference_container_GBps": REFERENCE_CONTAINER["inflate_out_GBps"]}
     if not args.no_cpu:
         t0 = time.perf_counter()
         done = 0

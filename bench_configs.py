@@ -379,6 +379,42 @@ def main():
             "lz_kernel_ms": round(k1[0], 2) if k1 else None,
             "cpu_python_zlib_level1_in_MBps_1thread": round(16 * each / 1e6 / t_cpu, 1),
             "cpu_python_zlib_level1_ratio": round(16 * each / cl1, 3)}
+        # ... and back on the device (zng_rocm_inflate_streams_dev, one wavefront per stream), every byte compared there;
+        # then the same plaintext as CPython level-6 streams (dynamic Huffman blocks), 64 distinct, repeated
+        clens = [int(v) for v in res[:, 0]]
+        plain = torch.empty(nstreams * each + 64, dtype=torch.uint8, device="cuda")
+        ib = inf.InflateDevBatch(batch.dst, batch.out_off, clens, plain, [i * each for i in range(nstreams)], [each] * nstreams)
+        back_ms = gpu_time_ms(ib.run, 3, torch)
+        rows = ib.results.cpu()
+        back_ok = bool((rows[:, 2] == 1).all()) and rows[:, 1].tolist() == clens and torch.equal(plain[:nstreams * each], src)
+        blobs = []
+        for i in range(64):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            blobs.append(c.compress(host[i * each:(i + 1) * each].tobytes()) + c.flush())
+        offs, pos = [], 0
+        for i in range(nstreams):
+            offs.append(pos)
+            pos += (len(blobs[i % 64]) + 15) & ~15
+        packed = np.zeros(pos + 16, dtype=np.uint8)
+        for i in range(nstreams):
+            b = blobs[i % 64]
+            packed[offs[i]:offs[i] + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        d_packed = torch.from_numpy(packed).cuda()
+        plain.zero_()
+        ib6 = inf.InflateDevBatch(d_packed, offs, [len(blobs[i % 64]) for i in range(nstreams)], plain,
+                                  [i * each for i in range(nstreams)], [each] * nstreams)
+        back6_ms = gpu_time_ms(ib6.run, 3, torch)
+        want6 = torch.from_numpy(host[:64 * each]).cuda().repeat(nstreams // 64) if nstreams % 64 == 0 else None
+        back6_ok = bool((ib6.results.cpu()[:, 2] == 1).all()) and (want6 is None or torch.equal(plain[:nstreams * each], want6))
+        report["cfg5_inflate_dev"] = {
+            "workload": "the %d streams above decoded on the device, one wavefront per stream; then the same plaintext "
+                        "as CPython zlib level-6 streams" % nstreams,
+            "own_streams": {"bit_exact": back_ok, "ms": round(back_ms, 2), "out_GBps": round(nstreams * each / 1e9 / (back_ms / 1e3), 2),
+                            "in_GBps": round(clen / 1e9 / (back_ms / 1e3), 2)},
+            "zlib_level6_streams": {"bit_exact": back6_ok, "ms": round(back6_ms, 2),
+                                    "out_GBps": round(nstreams * each / 1e9 / (back6_ms / 1e3), 2),
+                                    "ratio": round(64 * each / sum(len(b) for b in blobs), 3)},
+            "cpu_reference_container_out_GBps": [0.318, 0.516]}
 
     print(json.dumps(report, indent=1))
 
