@@ -186,3 +186,45 @@ def test_round_trip_of_the_level1_class_at_cfg5_size(inf):
     assert r[:, 1].tolist() == clen
     assert torch.equal(dst[:n * per], src)
     assert (dst[n * per:] == 0x5A).all()
+
+
+def test_mutated_streams_agree_with_the_oracle(inf):
+    """damaged streams: every status / message / output must be what the oracle inflater (the CPU restatement of
+    inflate.c + inftrees.c + inffast_tpl.h) says -- bit flips anywhere (headers, code-length codes, codes, extra bits),
+    byte substitutions, truncations, of streams with fixed, dynamic and stored blocks"""
+    rng = np.random.default_rng(2025)
+    seeds = [
+        _raw(synth.silesia_like(60000, seed=9).tobytes(), 6),
+        _raw(synth.silesia_like(40000, seed=10).tobytes(), 1),
+        _raw(b"abracadabra " * 3000, 9),
+        _raw(synth.silesia_like(30000, seed=12).tobytes(), 6, zlib.Z_FIXED),
+        _raw(rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes(), 6),           # stored blocks
+        _raw(bytes(rng.integers(0, 4, size=50000, dtype=np.uint8)), 6, zlib.Z_HUFFMAN_ONLY),
+    ]
+    streams = []
+    for s in seeds:
+        for _ in range(60):
+            b = bytearray(s)
+            kind = int(rng.integers(0, 4))
+            if kind == 0:                                   # one bit, biased to the front (block headers, tables)
+                pos = int(min(len(b) - 1, abs(rng.normal(0, 40)))) if rng.random() < 0.6 else int(rng.integers(0, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:                                 # a few random bytes
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 2:                                 # truncation
+                b = b[:int(rng.integers(0, len(b)))]
+            else:                                           # a flipped bit and a cut
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+                b = b[:int(rng.integers(len(b) // 2, len(b) + 1))]
+            streams.append(bytes(b))
+    cap = 200000
+    rows, outs = _run(inf, streams, [cap] * len(streams))
+    differ = []
+    for s, r, o in zip(streams, rows, outs):
+        ost, omsg, oout, oused = inflate_util.oracle_inflate(s, cap=cap)
+        if ost == -5 and r[0] == -5:
+            continue                                        # both ran out of input or room; the partial output is not compared
+        if (r[0], r[3]) != (ost, omsg) or (ost == 1 and (o != oout or r[2] != oused)):
+            differ.append((s[:16].hex(), len(s), r[:1] + r[3:], (ost, omsg)))
+    assert not differ, differ[:5]
