@@ -415,6 +415,22 @@ def main():
                                     "out_GBps": round(nstreams * each / 1e9 / (back6_ms / 1e3), 2),
                                     "ratio": round(64 * each / sum(len(b) for b in blobs), 3)},
             "cpu_reference_container_out_GBps": [0.318, 0.516]}
+        del ib, ib6, d_packed, plain
+        # the same many-stream job at pigz's default level: zng_rocm_deflate_streams_dev (chain walk + dynamic Huffman)
+        sb = dfl.StreamsBatch(src, [i * each for i in range(nstreams)], [each] * nstreams)
+        t0 = time.perf_counter()
+        cl6 = sb.run(level=6)
+        torch.cuda.synchronize()
+        t6 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        cl6 = sb.run(level=6)
+        torch.cuda.synchronize()
+        t6 = min(t6, time.perf_counter() - t0)
+        ok6 = all(zlib.decompressobj(-15).decompress(sb.compressed(i)) == host[i * each:(i + 1) * each].tobytes() for i in sample)
+        report["cfg5_level6"] = {
+            "workload": "%d independent 1 MiB streams at level 6 (zng_rocm_deflate_streams_dev), one GPU" % nstreams,
+            "round_trip_sample_ok": bool(ok6), "ratio": round(nstreams * each / sum(cl6), 3), "ms": round(t6 * 1e3, 1),
+            "input_GBps": round(nstreams * each / 1e9 / t6, 2), "cpu_reference_container_GBps": 0.044}
 
     print(json.dumps(report, indent=1))
 

@@ -258,6 +258,13 @@ int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8
                             size_t *out_len, void *stream);
 int    zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags,
                                   uint8_t *d_out, size_t out_cap, size_t *out_len, void *stream);
+/* Many independent streams (or independent blocks of one input) at one of the chain levels 1..9 -- the reference's
+ * many-stream model (test/pigz/CMakeLists.txt:123-200) at pigz's default level: the segments of ALL streams go through
+ * one set of launches per ~1 GiB of plaintext.  Per job as zng_rocm_deflate_block_dev (dict_len bytes of history in
+ * front of `in`, ZNG_ROCM_BLOCK_* flags, out_cap >= zng_rocm_deflate_bound(in_len)); synchronous; out_lens[i] (host) =
+ * compressed size of stream i.  The level-1 CLASS (static Huffman, one kernel) is zng_rocm_deflate_quick_dev. */
+int    zng_rocm_deflate_streams_dev(int level, const zng_rocm_stream_job *jobs, size_t njobs, size_t *out_lens,
+                                    void *stream);
 
 /* ---- inflate: host bitstream decode -> token stream -> device copy resolution -------------
  * The split of slot `inflate_fast` (inffast_tpl.h:53-318): the sequential Huffman decode loop

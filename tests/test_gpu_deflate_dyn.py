@@ -146,3 +146,56 @@ def test_three_gib_stream(mods):
     assert clen < n // 2
     with pytest.raises(Exception):
         dfl.deflate_dev(src, level=4, length=(1 << 32) - (64 << 10))      # beyond the 32-bit position format
+
+
+def test_many_streams_at_a_chain_level(mods):
+    """zng_rocm_deflate_streams_dev: ragged streams in one call (levels 1, 6, 9), each restored by CPython's zlib, by the
+    oracle inflater and -- all at once -- by the product's device inflater; byte-identical to the one-stream entry point
+    when the segment size agrees; a dictionary in front of a stream; pigz-style blocks of one input concatenating into
+    one stream"""
+    zr, dfl, inf = mods
+    torch = torch_mod()
+    rng = np.random.default_rng(77)
+    mix = synth.silesia_like(5 << 20, seed=43, seg_bytes=256 << 10).tobytes()
+    pieces = [mix[:1 << 20], mix[1 << 20:(1 << 20) + 300001], b"", b"z", mix[2 << 20:(2 << 20) + 70000],
+              b"\0" * 200000, rng.integers(0, 256, size=150000, dtype=np.uint8).tobytes(), mix[3 << 20:(3 << 20) + (700 << 10)]]
+    offs, pos = [], 0
+    for p in pieces:
+        offs.append(pos)
+        pos += (len(p) + 15) & ~15
+    host = np.zeros(pos + 16, dtype=np.uint8)
+    for o, p in zip(offs, pieces):
+        host[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    src = torch.from_numpy(host).cuda()
+    for level in (1, 6, 9):
+        b = dfl.StreamsBatch(src, offs, [len(p) for p in pieces])
+        clens = b.run(level=level)
+        comps = [b.compressed(i) for i in range(len(pieces))]
+        for p, c in zip(pieces, comps):
+            d = zlib.decompressobj(-15)
+            assert d.decompress(c) == p and d.eof and d.unused_data == b""
+            st, msg, out, used = inflate_util.oracle_inflate(c, cap=len(p) + 16)
+            assert (st, out, used) == (1, p, len(c)), msg
+        # back through the device inflater, all streams in one launch
+        plain = torch.full((pos + 64,), 0x77, dtype=torch.uint8, device="cuda")
+        ib = inf.InflateDevBatch(b.dst, b.out_off, clens, plain, offs, [len(p) for p in pieces])
+        ib.run()
+        rows = ib.rows()
+        assert all(r == (1, len(p), c, "") for r, p, c in zip(rows, pieces, clens)), rows
+        got = plain.cpu().numpy()
+        assert all(got[o:o + len(p)].tobytes() == p for o, p in zip(offs, pieces))
+    # ratio in the level-6 class
+    b = dfl.StreamsBatch(src, offs[:1], [len(pieces[0])])
+    assert len(pieces[0]) / b.run(level=6)[0] > 2.0
+    # pigz shape: 128 KiB blocks of one input, each primed with the 32 KiB before it, sync-flushed, concatenated
+    whole = mix[:1 << 20]
+    blk = 128 << 10
+    w = torch.from_numpy(np.frombuffer(whole + b"\0" * 16, dtype=np.uint8).copy()).cuda()
+    nb = len(whole) // blk
+    flags = [dfl.BLOCK_NOT_FINAL | dfl.BLOCK_SYNC_FLUSH] * (nb - 1) + [0]
+    pb = dfl.StreamsBatch(w, [i * blk for i in range(nb)], [blk] * nb, dict_len=[min(32768, i * blk) for i in range(nb)],
+                          flags=flags)
+    pb.run(level=6)
+    joined = b"".join(pb.compressed(i) for i in range(nb))
+    d = zlib.decompressobj(-15)
+    assert d.decompress(joined) == whole and d.eof

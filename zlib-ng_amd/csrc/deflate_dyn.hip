@@ -760,4 +760,124 @@ int zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, ui
     return ZNG_ROCM_OK;
 }
 
+// Many independent streams at one of the chain levels (the reference's many-stream model, test/pigz/CMakeLists.txt:123-200,
+// at pigz's default level): every stream is cut into segments as in zng_rocm_deflate_block_dev and the segments of ALL
+// streams go through ONE set of launches per round (a round holds up to ~1 GiB of plaintext: the matcher's selectors
+// are 4 bytes per input byte).  Synchronous, like zng_rocm_deflate_block_dev; out_lens is a host array.
+int zng_rocm_deflate_streams_dev(int level, const zng_rocm_stream_job *sjobs, size_t njobs, size_t *out_lens, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!njobs) return ZNG_ROCM_OK;
+    if (!sjobs || !out_lens) return ZNG_ROCM_EINVAL;
+    if (level < 1 || level > 9) {
+        set_error("level %d is outside 1..9 (level 0: zng_rocm_deflate_block_dev per stream)", level);
+        return ZNG_ROCM_EINVAL;
+    }
+    size_t total_in = 0;
+    for (size_t i = 0; i < njobs; ++i) {
+        const zng_rocm_stream_job &j = sjobs[i];
+        if (!j.out || (j.in_len && !j.in) || (j.dict_len && !j.in) || j.dict_len > kPrime ||
+            (j.flags & ~(uint32_t)(ZNG_ROCM_BLOCK_NOT_FINAL | ZNG_ROCM_BLOCK_SYNC_FLUSH)) ||
+            (uint64_t)j.in_len + j.dict_len >= (1ull << 32) - kSegBytes) {
+            set_error("job %zu: null buffer, dict_len above 32768, unknown flags, or a stream of 4 GiB and more", i);
+            return ZNG_ROCM_EINVAL;
+        }
+        if (j.out_cap < zng_rocm_deflate_bound(j.in_len)) {
+            set_error("job %zu: out_cap below zng_rocm_deflate_bound()", i);
+            return -5;
+        }
+        total_in += j.in_len;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dev;
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    static const uint32_t chains[10] = {0, 1, 4, 6, 24, 32, 128, 256, 1024, 4096};     // deflate.c:142-168
+    static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};
+    const uint32_t max_chain = chains[level] > 256 ? 256 : chains[level], good_match = goods[level];
+    const uint32_t seg_bytes = segment_bytes(total_in, ctx()->cus);
+    constexpr size_t kRoundBytes = 1ull << 30;
+
+    size_t first = 0;
+    while (first < njobs) {
+        // the streams of this round, and how many segments they make
+        size_t last = first, bytes = 0, nseg = 0;
+        while (last < njobs && (last == first || bytes + sjobs[last].in_len + sjobs[last].dict_len <= kRoundBytes)) {
+            bytes += sjobs[last].in_len + sjobs[last].dict_len + 8;
+            nseg += sjobs[last].in_len ? (sjobs[last].in_len + seg_bytes - 1) / seg_bytes : 1;
+            ++last;
+        }
+        SegJob *d_jobs = nullptr, *jobs = nullptr;
+        uint32_t *d_sel = nullptr, *d_seg_len = nullptr, *lens = nullptr;
+        uint64_t *d_dst_off = nullptr, *offs = nullptr;
+        uint8_t *d_slots = nullptr;
+        if (int rc = host_tables_acquire(ws)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynSegLenHost, nseg * sizeof(uint32_t), true, (void **)&lens)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynDstOffHost, nseg * sizeof(uint64_t), true, (void **)&offs)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * sizeof(uint32_t), false, (void **)&d_seg_len)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynDstOff, nseg * sizeof(uint64_t), false, (void **)&d_dst_off)) return rc;
+        if (int rc = scratch_reserve(ws, kScrDynSel, (bytes + 1024 * (last - first) + 1024) * sizeof(uint32_t), false, (void **)&d_sel))
+            return rc;
+        size_t slot_total = 0, k = 0;
+        uint64_t sel_at = 0;
+        for (size_t s = first; s < last; ++s) {
+            const zng_rocm_stream_job &j = sjobs[s];
+            const uint32_t dict = j.dict_len;
+            const bool final_block = (j.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
+            const size_t n = j.in_len ? (j.in_len + seg_bytes - 1) / seg_bytes : 1;
+            sel_at = (sel_at + 3u) & ~(uint64_t)3u;
+            for (size_t i = 0; i < n; ++i, ++k) {
+                const uint32_t a = dict + (uint32_t)(i * seg_bytes);
+                const uint32_t b = dict + (uint32_t)((i + 1) * (size_t)seg_bytes < j.in_len ? (i + 1) * (size_t)seg_bytes : j.in_len);
+                jobs[k].in = j.in - dict;
+                jobs[k].seg_start = a;
+                jobs[k].seg_end = b;
+                jobs[k].out_cap = (uint32_t)seg_slot_bytes(b - a);
+                jobs[k].is_last = (i + 1 == n && final_block) ? 1 : 0;
+                jobs[k].sel_off = sel_at + (4u - dict % 4u) % 4u;         // selector of a segment's first byte stays 16-byte aligned
+                jobs[k].out = (uint8_t *)slot_total;
+                slot_total += jobs[k].out_cap;
+            }
+            sel_at += (uint64_t)j.in_len + dict + 1024 + 4;
+        }
+        if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
+        for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
+        ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
+        ZR_LAUNCH_TRACED(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), st, d_jobs, d_sel, max_chain, good_match);
+        ZR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_sel, d_seg_len);
+        ZR_HIP(hipGetLastError());
+        ZR_HIP(hipMemcpyAsync(lens, d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        ZR_HIP(hipStreamSynchronize(st));
+        // every segment's place: absolute addresses inside its stream's output buffer
+        k = 0;
+        for (size_t s = first; s < last; ++s) {
+            const zng_rocm_stream_job &j = sjobs[s];
+            const size_t n = j.in_len ? (j.in_len + seg_bytes - 1) / seg_bytes : 1;
+            uint64_t total = 0;
+            for (size_t i = 0; i < n; ++i, ++k) {
+                offs[k] = (uint64_t)(uintptr_t)j.out + total;
+                total += lens[k];
+            }
+            if (total > j.out_cap) {
+                set_error("job %zu: compressed size %llu exceeds out_cap", s, (unsigned long long)total);
+                return -5;
+            }
+            out_lens[s] = (size_t)total;
+        }
+        ZR_HIP(hipMemcpyAsync(d_dst_off, offs, nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_segments_kernel, dim3(4, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off,
+                           (uint8_t *)nullptr);
+        ZR_HIP(hipGetLastError());
+        ZR_HIP(hipStreamSynchronize(st));
+        first = last;
+    }
+    return ZNG_ROCM_OK;
+}
+
 }  // extern "C"

@@ -76,6 +76,46 @@ def deflate_bound(n):
     return rocm.lib().zng_rocm_deflate_bound(n)
 
 
+class StreamsBatch:
+    """Many independent device-resident streams at a chain level (zng_rocm_deflate_streams_dev).  Layout as QuickBatch:
+    stream i = src[in_off[i] : in_off[i] + in_len[i]] with dict_len[i] bytes of history in front of it; the compressed
+    streams land in `dst` at out_off[i] (bound-sized slots); run() returns the list of compressed lengths."""
+
+    def __init__(self, src, in_off, in_len, dict_len=None, flags=None):
+        import torch
+        rocm._need_init()
+        self.src = src
+        self.n = len(in_len)
+        self.in_len = [int(v) for v in in_len]
+        self.bounds = [(deflate_bound(v) + 15) & ~15 for v in self.in_len]
+        self.out_off, total = [], 0
+        for b in self.bounds:
+            self.out_off.append(total)
+            total += b
+        self.dst = torch.empty(max(total, 16), dtype=torch.uint8, device=src.device)
+        self.jobs = (StreamJob * self.n)()
+        bi, bo = src.data_ptr(), self.dst.data_ptr()
+        for i in range(self.n):
+            self.jobs[i].dict_len = 0 if dict_len is None else int(dict_len[i])
+            self.jobs[i].flags = 0 if flags is None else int(flags[i])
+            if self.jobs[i].dict_len > int(in_off[i]):
+                raise ValueError("the dictionary must lie inside src, in front of the stream")
+            self.jobs[i].in_ptr = bi + int(in_off[i])
+            self.jobs[i].out_ptr = bo + self.out_off[i]
+            self.jobs[i].in_len = self.in_len[i]
+            self.jobs[i].out_cap = self.bounds[i]
+        self.out_lens = (C.c_size_t * self.n)()
+
+    def run(self, level=6, stream=None):
+        rocm._check(rocm.lib().zng_rocm_deflate_streams_dev(level, C.byref(self.jobs), self.n, C.byref(self.out_lens),
+                                                            rocm._stream_ptr(stream)), "zng_rocm_deflate_streams_dev")
+        return [int(v) for v in self.out_lens]
+
+    def compressed(self, i):
+        o = self.out_off[i]
+        return self.dst[o:o + int(self.out_lens[i])].cpu().numpy().tobytes()
+
+
 def deflate_dev(src, level=6, length=None, offset=0, stream=None, dict_len=0, flags=0):
     """one large device-resident stream (or, with dict_len / flags, one BLOCK of a longer stream whose dict_len
     bytes of history sit in src in front of `offset`) -> (uint8 CUDA tensor with raw deflate, compressed length).

@@ -83,6 +83,7 @@ _PROTOS = {
                                              C.POINTER(C.c_size_t), C.c_void_p]),
     "zng_rocm_deflate_quick_bound": (C.c_size_t, [C.c_size_t]),
     "zng_rocm_deflate_quick_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_deflate_streams_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_inflate_tokens_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zng_rocm_inflate_tokens_decode_window": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "zng_rocm_inflate_resolve_window_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
