@@ -181,18 +181,40 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     idx = torch.arange(first, first + count, device=dev) % distinct
     src = d_base[idx].reshape(-1).contiguous() if count else torch.zeros(16, dtype=torch.uint8, device=dev)
     del d_base
-    batch = dfl.QuickBatch(src, [i * each for i in range(count)], [each] * count)
+    # Few streams per GPU (N > 1: the job is fixed, the shard shrinks) would leave most of a GPU idle: one workgroup per
+    # stream, eight per CU.  Then every stream is compressed as pigz does it (pigz.c: blocks primed with the 32 KiB before
+    # them, each closed by a sync-flush marker, concatenated): `blocks` blocks per stream keep >= 2048 jobs on the GPU.
+    blocks = 1
+    while count and count * blocks < 2048 and blocks < 8:
+        blocks *= 2
+    blk = each // blocks
+    offs = [i * each + b * blk for i in range(count) for b in range(blocks)]
+    dicts = [min(32768, b * blk) for i in range(count) for b in range(blocks)]
+    flg = [(dfl.BLOCK_NOT_FINAL | dfl.BLOCK_SYNC_FLUSH) if b + 1 < blocks else 0 for i in range(count) for b in range(blocks)]
+    batch = dfl.QuickBatch(src, offs, [blk] * (count * blocks), dict_len=dicts, flags=flg)
     ulen = torch.full((count,), each, dtype=torch.int64, device=dev)
+
+    def stream_rows():
+        """{clen, adler32} per STREAM from the per-block rows: lengths add, Adler-32 values combine (adler32_combine_,
+        adler32.c:32-54, vectorised over the streams: one step per block)"""
+        res = batch.results.to(torch.int64) & 0xffffffff
+        if blocks == 1:
+            return res[:, 0], res[:, 1]
+        r = res.view(count, blocks, 2)
+        a, bsum = r[:, 0, 1] & 0xffff, r[:, 0, 1] >> 16
+        for k in range(1, blocks):
+            a2, b2 = r[:, k, 1] & 0xffff, r[:, k, 1] >> 16
+            bsum = (bsum + b2 + (blk % 65521) * ((a + 65520) % 65521)) % 65521
+            a = (a + a2 + 65520) % 65521
+        return r[:, :, 0].sum(1), a | (bsum << 16)
     per = (args.streams + world - 1) // world
     padded = torch.zeros((per, 3), dtype=torch.int64, device=dev)
     gathered = torch.zeros((world * per * 3,), dtype=torch.int64, device=dev)
     state = {}
 
     def exchange():
-        res = batch.results.to(torch.int64) & 0xffffffff
         if count:
-            padded[:count, 0] = res[:, 0]
-            padded[:count, 1] = res[:, 1]
+            padded[:count, 0], padded[:count, 1] = stream_rows()
             padded[:count, 2] = ulen
         if world > 1 and not rehearse:
             dist.all_gather_into_tensor(gathered, padded.view(-1))       # RCCL, 24 bytes per stream
@@ -243,19 +265,32 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     # Adler-32 row equals that of its slice
     res = batch.results.cpu()
     adlers = [zlib.adler32(base[k * each:(k + 1) * each].tobytes()) for k in range(distinct)]
+    if count:
+        s_clen, s_adler = (v.cpu() for v in stream_rows())
     for i in range(count):
-        assert (int(res[i, 1]) & 0xffffffff) == adlers[(first + i) % distinct], "adler32 row %d" % (first + i)
+        assert int(s_adler[i]) == adlers[(first + i) % distinct], "adler32 row %d" % (first + i)
     for i in ([0, count - 1] if count else []):
         k = (first + i) % distinct
-        assert zlib.decompressobj(-15).decompress(batch.compressed(i, res)) == base[k * each:(k + 1) * each].tobytes()
+        joined = b"".join(batch.compressed(i * blocks + b, res) for b in range(blocks))     # the stream = its blocks in order
+        assert len(joined) == int(s_clen[i])
+        assert zlib.decompressobj(-15).decompress(joined) == base[k * each:(k + 1) * each].tobytes()
     # ... and back, on the device: this rank's compressed streams through zng_rocm_inflate_streams_dev (one wavefront per
     # stream: block headers, table build, Huffman decode and copies), compared with the plaintext on the device
     inf = importlib.import_module("zlib-ng_amd.inflate")
     back_ms, back_kernel_ms = float("nan"), float("nan")
     if count:
         plain = torch.empty(count * each + 64, dtype=torch.uint8, device=dev)
-        clens = [int(v) for v in res[:, 0]]
-        ib = inf.InflateDevBatch(batch.dst, batch.out_off, clens, plain, [i * each for i in range(count)], [each] * count)
+        clens = [int(v) for v in s_clen]
+        if blocks == 1:
+            comp, comp_off = batch.dst, batch.out_off
+        else:                                   # lay every stream's blocks end to end (not timed)
+            comp = torch.cat([batch.dst[batch.out_off[j]:batch.out_off[j] + int(res[j, 0])] for j in range(count * blocks)] +
+                             [torch.zeros(16, dtype=torch.uint8, device=dev)])
+            comp_off, at = [], 0
+            for c in clens:
+                comp_off.append(at)
+                at += c
+        ib = inf.InflateDevBatch(comp, comp_off, clens, plain, [i * each for i in range(count)], [each] * count)
         ib.run()
         fence()
         reps = 3
@@ -282,12 +317,15 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
     assert int(table[:, 2].sum()) == total_in and int(state["offsets"][-1] + table[-1, 0]) == total_out
     k_ms = statistics.mean(kernel_ms) if kernel_ms else float("nan")
     local_bytes = count * each + int(res[:, 0].to(torch.int64).sum())
+    layout = "one static block per stream" if blocks == 1 else \
+        "%d blocks of %d KiB per stream, each primed with the 32 KiB before it and closed by a sync-flush marker (pigz), " \
+        "the blocks of a stream concatenate into its deflate stream" % (blocks, blk >> 10)
     out = {
         "workload": "configs[4]: %d independent 1 MiB streams, deflate level-1 class (static Huffman), sharded %d-way, "
                     "{clen, adler32, ulen} table all-gathered" % (args.streams, world),
         "value": round(total_in / 1e9 / (elapsed / steps), 2), "unit": "GB/s", "scaling": "strong",
         "n_gpus": world, "steps": steps, "warmup": max(1, warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
-        "streams_per_gpu": count, "ratio": round(total_in / total_out, 3),
+        "streams_per_gpu": count, "blocks_per_stream": blocks, "layout": layout, "ratio": round(total_in / total_out, 3),
         "exchange_us": round(exchange_us, 1),
         "exchange": "all_gather of %d B per rank (24 B per stream) + exclusive scan of clen on every rank; inside "
                     "ms_per_step, also timed alone here" % (per * 24),
@@ -465,6 +503,7 @@ def main():
                     "roofline": s["roofline"], "exchange_us": s["exchange_us"]}
             if "cpu_baseline" in s:
                 line["cpu_baseline"] = s["cpu_baseline"]
+            line["inflate_back"] = s["inflate_back"]
             emit(line)
         if world > 1:
             dist.barrier()
