@@ -340,6 +340,10 @@ def run_streams(args, zr, par, torch, dist, dev, world, rank, rehearse, steps, w
                     "compared with the plaintext on the device" % args.streams,
         "value": round(total_in / 1e9 / (back_ms / 1e3), 2), "unit": "GB/s of output", "ms": round(back_ms, 3),
         "kernel_ms_rank0": round(back_kernel_ms, 3), "bit_exact": True,
+        "roofline": {"bound": "hbm", "kernel": "zr::inflate_streams_kernel (one wavefront per stream; scalar-issue bound, DESIGN.md 3.8)",
+                     "achieved": round(local_bytes / 1e9 / (back_kernel_ms / 1e3), 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(local_bytes / 1e9 / (back_kernel_ms / 1e3) / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": local_bytes, "avg_kernel_ms": round(back_kernel_ms, 3)},
         "reference_container_GBps": REFERENCE_CONTAINER["inflate_out_GBps"]}
     if not args.no_cpu:
         t0 = time.perf_counter()
