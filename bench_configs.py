@@ -416,6 +416,29 @@ def main():
                                     "ratio": round(64 * each / sum(len(b) for b in blobs), 3)},
             "cpu_reference_container_out_GBps": [0.318, 0.516]}
         del ib, ib6, d_packed, plain
+        # a check value per stream, all in one pass (zng_rocm_checksums_dev)
+        ck = torch.zeros((nstreams, 2), dtype=torch.int32, device="cuda")
+        ck_off, ck_len = [i * each for i in range(nstreams)], [each] * nstreams
+        ck_ms = {w: gpu_time_ms(lambda w=w: zr.checksums_dev(w, src, ck_off, ck_len, ck), 3, torch) for w in (1, 2, 3)}
+        ck_kernel = {}
+        for w in (1, 2, 3):
+            zr.trace_begin(3)
+            for _ in range(3):
+                zr.checksums_dev(w, src, ck_off, ck_len, ck)
+            ck_kernel[w] = statistics.mean(zr.trace_end(3))
+        ckh = ck.cpu().numpy().astype(np.int64) & 0xffffffff
+        ck_ok = all(ckh[i, 0] == zlib.adler32(host[i * each:(i + 1) * each].tobytes()) and
+                    ckh[i, 1] == zlib.crc32(host[i * each:(i + 1) * each].tobytes()) for i in sample)
+        report["cfg5_checksums"] = {
+            "workload": "adler32 / crc32 / both of each of the %d streams, one pass for all (zng_rocm_checksums_dev; the "
+                        "time includes building and uploading the %d descriptors)" % (nstreams, nstreams),
+            "bit_exact_sample": bool(ck_ok),
+            "adler32": {"ms": round(ck_ms[1], 3), "kernel_ms": round(ck_kernel[1], 3),
+                        "kernel_frac_of_8TBps": round(nstreams * each / 1e9 / (ck_kernel[1] / 1e3) / 8000, 3)},
+            "crc32": {"ms": round(ck_ms[2], 3), "kernel_ms": round(ck_kernel[2], 3),
+                      "kernel_frac_of_8TBps": round(nstreams * each / 1e9 / (ck_kernel[2] / 1e3) / 8000, 3)},
+            "both": {"ms": round(ck_ms[3], 3), "kernel_ms": round(ck_kernel[3], 3),
+                     "kernel_frac_of_8TBps": round(nstreams * each / 1e9 / (ck_kernel[3] / 1e3) / 8000, 3)}}
         # the same many-stream job at pigz's default level: zng_rocm_deflate_streams_dev (chain walk + dynamic Huffman)
         sb = dfl.StreamsBatch(src, [i * each for i in range(nstreams)], [each] * nstreams)
         t0 = time.perf_counter()

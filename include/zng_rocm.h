@@ -194,6 +194,19 @@ int zng_rocm_longest_match_slow_dev(const zng_rocm_deflate_view *d_views, size_t
                                     const uint16_t *d_cur_match, uint32_t *d_len_out, uint32_t *d_match_start_out,
                                     void *stream);
 
+/* Many messages in one pass -- the many-stream form of adler32 / crc32 (every block or stream of a pigz-style job has
+ * its own check value, combined afterwards with zng_rocm_*_combine_dev): one workgroup per message up to 16 MiB, more
+ * above, one set of launches for all of them.  which: 1 = Adler-32, 2 = CRC-32, 3 = both; per job the device buffer, its
+ * length (< 16 GiB) and the seeds (adler32.c:11 / crc32.c semantics: 1 and 0 start a new check).  d_out2 receives two
+ * words per job {adler, crc}; the word not asked for is left untouched.  Asynchronous on `stream`; jobs is a host array. */
+typedef struct zng_rocm_check_job {
+    const void *buf;      /* device */
+    uint64_t    len;
+    uint32_t    adler;    /* seed */
+    uint32_t    crc;      /* seed */
+} zng_rocm_check_job;
+int zng_rocm_checksums_dev(int which, const zng_rocm_check_job *jobs, size_t njobs, uint32_t *d_out2, void *stream);
+
 /* ---- inflate-side copy primitive ------------------------------------------
  * slot `chunkmemset_safe` (chunkset_tpl.h:229-261) as a batch of INDEPENDENT copies inside one device
  * buffer: copy i writes out = d_base + d_out_off[i], reads from = d_base + d_from_off[i], with the

@@ -334,3 +334,53 @@ def test_slots_from_a_thread_that_never_selected_the_device(zr, oracle):
         t.start()
         t.join()
     assert got == [want] * 6
+
+
+def test_many_messages_in_one_pass(zr, oracle):
+    """zng_rocm_checksums_dev: ragged messages at every 16-byte phase, empty and tiny ones, non-canonical seeds, more
+    messages than one grid holds rows, one message large enough for several workgroups -- each value bit-exact against
+    the oracle (adler32_c.c / crc32_braid_c.c restated) and CPython's zlib"""
+    import zlib
+    torch = torch_mod()
+    rng = np.random.default_rng(404)
+    total = 96 << 20
+    host = rng.integers(0, 256, size=total + 64, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    lens = [0, 1, 2, 15, 16, 17, 31, 4095, 16383, 16384, 16385, 65536 + 7, (1 << 20) + 3, (1 << 20), 300001]
+    lens += [int(v) for v in rng.integers(0, 70000, size=200)]
+    lens += [(40 << 20) + 11]                                           # several workgroups for this one
+    offs, pos = [], 3
+    for i, n in enumerate(lens):
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 37))                             # every alignment
+    assert pos < total
+    adlers = [1] * len(lens)
+    crcs = [0] * len(lens)
+    for i in range(0, len(lens), 7):                                    # chained / non-canonical seeds
+        adlers[i] = int(rng.integers(0, 1 << 32))
+        crcs[i] = int(rng.integers(0, 1 << 32))
+    for which in (1, 2, 3):
+        out = torch.full((len(lens), 2), -1, dtype=torch.int32, device="cuda")
+        zr.checksums_dev(which, dev, offs, lens, out, adlers, crcs)
+        got = out.cpu().numpy().astype(np.int64) & 0xffffffff
+        for i, (o, n) in enumerate(zip(offs, lens)):
+            if which & 1:
+                assert got[i, 0] == oracle.oracle_adler32(adlers[i], host.ctypes.data + o, n), (which, i, n)
+            else:
+                assert got[i, 0] == 0xffffffff                          # untouched
+            if which & 2:
+                assert got[i, 1] == oracle.oracle_crc32_braid(crcs[i], host.ctypes.data + o, n), (which, i, n)
+            else:
+                assert got[i, 1] == 0xffffffff
+    i = lens.index((1 << 20) + 3)
+    seg = host[offs[i]:offs[i] + lens[i]].tobytes()
+    assert got[i, 0] == zlib.adler32(seg, adlers[i]) and got[i, 1] == zlib.crc32(seg, crcs[i])
+    # more rows than one launch holds (32768): 40000 messages of 4 KiB
+    n = 40000
+    offs2 = [i * 2048 + (i % 13) for i in range(n)]
+    out = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    zr.checksums_dev(3, dev, offs2, [4096] * n, out)
+    got = out.cpu().numpy().astype(np.int64) & 0xffffffff
+    for i in (0, 1, 32767, 32768, 39999):
+        seg = host[offs2[i]:offs2[i] + 4096].tobytes()
+        assert got[i, 0] == zlib.adler32(seg) and got[i, 1] == zlib.crc32(seg), i

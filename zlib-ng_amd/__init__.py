@@ -18,6 +18,6 @@ from .rocm import (  # noqa: F401
     ZngRocmError, lib, lib_path, build, init, available, device_count,
     adler32, crc32, adler32_z, crc32_z, adler32_fold_copy,
     adler32_combine, crc32_combine, crc32_combine_gen, crc32_combine_op,
-    adler32_dev, crc32_dev, adler32_crc32_dev, fold_copy_dev,
+    adler32_dev, crc32_dev, adler32_crc32_dev, fold_copy_dev, checksums_dev,
     adler32_combine_dev, crc32_combine_dev, combine_rows_dev, reserve_cus, Crc32Fold, trace_begin, trace_end,
 )

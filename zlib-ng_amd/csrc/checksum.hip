@@ -150,4 +150,100 @@ int zng_rocm_reserve_cus(int n) {
     return ZNG_ROCM_OK;
 }
 
+// Many messages in one pass: the many-stream form of the checksum slots (a pigz-style job checks every block / stream,
+// pigz.c; per-stream launches would be launch-bound: two launches per message).  Grid row m of the streaming kernel is
+// message m (its descriptor read from an array instead of the kernel arguments), one workgroup per message up to
+// 16 MiB, more above; one finalize workgroup per message.  which: 1 = Adler-32, 2 = CRC-32, 3 = both.
+// d_out2: two words per message (adler, crc; the one not asked for is left untouched).
+int zng_rocm_checksums_dev(int which, const zng_rocm_check_job *jobs, size_t njobs, uint32_t *d_out2, void *stream) {
+    Context *c = ctx();
+    if (!c) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!njobs) return ZNG_ROCM_OK;
+    if (which < 1 || which > 3 || !jobs || !d_out2) return ZNG_ROCM_EINVAL;
+    const bool do_adler = (which & 1) != 0, do_crc = (which & 2) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dev;
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    size_t max_units = 1;
+    for (size_t i = 0; i < njobs; ++i) {
+        if ((!jobs[i].buf && jobs[i].len) || (jobs[i].len >> 34)) {
+            set_error("job %zu: null buffer or more than 16 GiB", i);
+            return ZNG_ROCM_EINVAL;
+        }
+        const size_t u = (size_t)((jobs[i].len + 15 + kUnitBytes) / kUnitBytes);
+        if (u > max_units) max_units = u;
+    }
+    // workgroups per message: one up to 1024 units (16 MiB), then as many as keep every workgroup at <= 1024 units
+    size_t G = (max_units + 1023) / 1024;
+    if (G > (size_t)c->cus) G = (size_t)c->cus;
+    constexpr size_t kRows = 32768;                     // grid.y per launch
+    const size_t per = sizeof(StreamArgs) + sizeof(FinalArgs);
+    const size_t rows_max = njobs < kRows ? njobs : kRows;
+    uint8_t *d_msg = nullptr, *h_msg = nullptr;
+    Partial *d_part = nullptr;
+    if (int rc = scratch_reserve(ws, kScrCheckMessages, rows_max * per, false, (void **)&d_msg)) return rc;
+    if (int rc = scratch_reserve(ws, kScrCheckPartials, rows_max * G * sizeof(Partial), false, (void **)&d_part)) return rc;
+    for (size_t first = 0; first < njobs; first += kRows) {
+        const size_t rows = njobs - first < kRows ? njobs - first : kRows;
+        if (int rc = host_tables_acquire(ws)) return rc;
+        if (int rc = scratch_reserve(ws, kScrCheckMessagesHost, rows_max * per, true, (void **)&h_msg)) return rc;
+        StreamArgs *sa = reinterpret_cast<StreamArgs *>(h_msg);
+        FinalArgs *fa = reinterpret_cast<FinalArgs *>(h_msg + rows * sizeof(StreamArgs));
+        for (size_t r = 0; r < rows; ++r) {
+            const zng_rocm_check_job &j = jobs[first + r];
+            const uintptr_t p = (uintptr_t)j.buf;
+            const uintptr_t a0 = p & ~(uintptr_t)15;
+            const uintptr_t tail_base = (p + j.len) & ~(uintptr_t)15;
+            StreamArgs &s = sa[r];
+            s.a0 = (const uint8_t *)a0;
+            s.dst0 = nullptr;
+            s.n = (long long)j.len;
+            s.body = (long long)(tail_base - a0);
+            s.nunits = (s.body + kUnitBytes - 1) / kUnitBytes;
+            s.head = (int)(p - a0);
+            s.tail = (int)((p + j.len) - tail_base);
+            s.phase_stamps = nullptr;
+            for (int k = 0; k < 4; ++k)
+                for (int i = 0; i < 8; ++i) {
+                    s.bits.stride[k][i] = c->host_tables.stride_tab[k][1u << i];
+                    s.bits.x32[k][i] = c->host_tables.x32_tab[k][1u << i];
+                }
+            FinalArgs &f = fa[r];
+            f.tail_base = (const uint8_t *)tail_base;
+            f.tail_dst = nullptr;
+            f.n = s.n;
+            f.nunits = s.nunits;
+            f.tail_lo = s.body == 0 ? s.head : 0;
+            f.tail_hi = s.tail;
+            if (j.len == 0) f.tail_lo = f.tail_hi = 0;
+            f.groups = (int)G;
+            f.adler_seed = j.adler;
+            f.crc_seed = j.crc;
+            f.crc_len_pow = do_crc ? xpow_bytes(c->host_tables.pow_tab, (uint64_t)j.len) : 0u;
+            f.adler_seed_ptr = nullptr;
+            f.crc_seed_ptr = nullptr;
+            f.do_adler = do_adler;
+            f.do_crc = do_crc;
+        }
+        ZR_HIP(hipMemcpyAsync(d_msg, h_msg, rows * per, hipMemcpyHostToDevice, st));
+        if (int rc = host_tables_release(ws, st)) return rc;
+        const StreamArgs *d_sa = reinterpret_cast<const StreamArgs *>(d_msg);
+        const FinalArgs *d_fa = reinterpret_cast<const FinalArgs *>(d_msg + rows * sizeof(StreamArgs));
+        dim3 grid((unsigned)G, (unsigned)rows), block(kWgThreads);
+        if (do_adler && do_crc) ZR_LAUNCH_TRACED((stream_kernel_batch<true, true>), grid, block, st, d_sa, c->tables, d_part);
+        else if (do_adler) ZR_LAUNCH_TRACED((stream_kernel_batch<true, false>), grid, block, st, d_sa, c->tables, d_part);
+        else ZR_LAUNCH_TRACED((stream_kernel_batch<false, true>), grid, block, st, d_sa, c->tables, d_part);
+        ZR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(finalize_kernel_batch, dim3((unsigned)rows), dim3(256), 0, st, d_fa, c->tables, d_part,
+                           d_out2 + 2 * first);
+        ZR_HIP(hipGetLastError());
+    }
+    return ZNG_ROCM_OK;
+}
+
 }  // extern "C"

@@ -191,9 +191,12 @@ constexpr int kVarEarlyRows   = 768;  // two bits: how many rows of group 0 are 
 constexpr int kCrcVariant = kVarFoldX32 | kVarBuildTables | kVarLdsBarrier | kVarByteAddr | kVarDirectImage | kVarTreeEpilogue;
 
 // DO_ADLER / DO_CRC select the checksums, COPY additionally stores every piece (fold_copy).
-template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false, int UNROLL = 4>
-__global__ __launch_bounds__(kWgThreads)
-void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
+// The kernel body: workgroup `g` of the `G` that share the message `args`.  Two entry points below: one message per
+// launch (stream_kernel, the message in the kernel arguments) and many messages per launch (stream_kernel_batch, one
+// descriptor per grid row -- the many-stream form of the same pass).
+template <bool DO_ADLER, bool DO_CRC, bool COPY, int V, bool PROFILE, int UNROLL>
+__device__ __forceinline__ void stream_body(const StreamArgs &args, const DeviceTables *__restrict__ tabs,
+                                            Partial *__restrict__ partials, const long long G, const long long g) {
     // 64 KiB alignment: with kVarByteAddr byte 1 of a lookup address must be free for the index (braid_step_bytes)
     __shared__ __attribute__((aligned(65536))) uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
     // linear copies: the four stride tables, the byte table, the four x^32 tables
@@ -206,7 +209,7 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     const uint32_t rep = t & 31;
     auto stamp = [&](int k) {
         if constexpr (PROFILE) {
-            if (t == 0) args.phase_stamps[8 * blockIdx.x + k] = wall_clock64();
+            if (t == 0) args.phase_stamps[8 * g + k] = wall_clock64();
         }
     };
     stamp(0);
@@ -220,7 +223,6 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     }
 
     // contiguous run of units for this workgroup
-    const long long G = gridDim.x, g = blockIdx.x;
     const long long q = args.nunits / G, r = args.nunits % G;
     const long long u_lo = g * q + (g < r ? g : r);
     const long long u_hi = u_lo + q + (g < r ? 1 : 0);
@@ -690,6 +692,21 @@ void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Parti
     stamp(5);
 }
 
+template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false, int UNROLL = 4>
+__global__ __launch_bounds__(kWgThreads)
+void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
+    stream_body<DO_ADLER, DO_CRC, COPY, V, PROFILE, UNROLL>(args, tabs, partials, gridDim.x, blockIdx.x);
+}
+
+// grid = (workgroups per message, messages): message blockIdx.y, its partials at partials[blockIdx.y * gridDim.x ...]
+template <bool DO_ADLER, bool DO_CRC, int V = kCrcVariant>
+__global__ __launch_bounds__(kWgThreads)
+void stream_kernel_batch(const StreamArgs *__restrict__ messages, const DeviceTables *__restrict__ tabs,
+                         Partial *__restrict__ partials) {
+    stream_body<DO_ADLER, DO_CRC, false, V, false, 4>(messages[blockIdx.y], tabs, partials + (size_t)blockIdx.y * gridDim.x,
+                                                      gridDim.x, blockIdx.x);
+}
+
 struct FinalArgs {
     const uint8_t *tail_base;   // granule holding the trailing bytes
     uint8_t       *tail_dst;    // COPY: where those bytes go (else nullptr)
@@ -708,9 +725,9 @@ struct FinalArgs {
     int            do_adler, do_crc;
 };
 
-__global__ __launch_bounds__(256)
-void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const Partial *__restrict__ partials,
-                     uint32_t *__restrict__ out_adler, uint32_t *__restrict__ out_crc) {
+__device__ __forceinline__
+void finalize_body(const FinalArgs &fa, const DeviceTables *__restrict__ tabs, const Partial *__restrict__ partials,
+                   uint32_t *__restrict__ out_adler, uint32_t *__restrict__ out_crc) {
     __shared__ uint32_t red[3][4];
     const int t = threadIdx.x;
     const long long G = fa.groups;
@@ -772,5 +789,21 @@ void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const 
         }
     }
 }
+
+__global__ __launch_bounds__(256)
+void finalize_kernel(FinalArgs fa, const DeviceTables *__restrict__ tabs, const Partial *__restrict__ partials,
+                     uint32_t *__restrict__ out_adler, uint32_t *__restrict__ out_crc) {
+    finalize_body(fa, tabs, partials, out_adler, out_crc);
+}
+
+// one workgroup per message: message blockIdx.x, `groups` partials each, results at out2[2 * message] (adler, crc)
+__global__ __launch_bounds__(256)
+void finalize_kernel_batch(const FinalArgs *__restrict__ messages, const DeviceTables *__restrict__ tabs,
+                           const Partial *__restrict__ partials, uint32_t *__restrict__ out2) {
+    const FinalArgs fa = messages[blockIdx.x];
+    finalize_body(fa, tabs, partials + (size_t)blockIdx.x * fa.groups, out2 + 2 * (size_t)blockIdx.x,
+                  out2 + 2 * (size_t)blockIdx.x + 1);
+}
+
 
 }  // namespace zr

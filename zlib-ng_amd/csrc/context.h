@@ -63,6 +63,9 @@ enum ScratchSlot {
     kScrInflateHost,        // pinned token staging of the batched inflate
     kScrInflateDevJobs,     // device: InflateJobDev[] of zng_rocm_inflate_streams_dev
     kScrInflateDevJobsHost, // pinned
+    kScrCheckMessages,      // device: StreamArgs[] | FinalArgs[] of zng_rocm_checksums_dev
+    kScrCheckMessagesHost,  // pinned
+    kScrCheckPartials,      // device: Partial[] (messages x workgroups per message)
     kScrCount
 };
 

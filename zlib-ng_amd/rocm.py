@@ -56,6 +56,7 @@ _PROTOS = {
     "zng_rocm_adler32_crc32_dev": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_fold_copy_dev": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p]),
+    "zng_rocm_checksums_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_adler32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_crc32_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_reserve_cus": (C.c_int, [C.c_int]),
@@ -292,6 +293,27 @@ def fold_copy_dev(which, dst, src, out2, adler=1, crc=0, length=None, src_offset
     _check(lib().zng_rocm_fold_copy_dev(which, adler & 0xffffffff, crc & 0xffffffff, _dev_ptr(dst, dst_offset),
                                         _dev_ptr(src, src_offset), n, _dev_ptr(out2), _stream_ptr(stream)),
            "zng_rocm_fold_copy_dev")
+
+
+class CheckJob(C.Structure):
+    """zng_rocm_check_job"""
+    _fields_ = [("buf", C.c_void_p), ("len", C.c_uint64), ("adler", C.c_uint32), ("crc", C.c_uint32)]
+
+
+def checksums_dev(which, buf, offsets, lengths, out2, adlers=None, crcs=None, stream=None):
+    """many messages of one uint8 CUDA tensor in one pass: message i = buf[offsets[i] : offsets[i] + lengths[i]];
+    out2: int32/uint32 CUDA tensor [n, 2] <- {adler32, crc32} (which: 1 adler, 2 crc, 3 both).  Async on `stream`."""
+    _need_init()
+    n = len(lengths)
+    jobs = (CheckJob * n)()
+    base = buf.data_ptr()
+    for i in range(n):
+        jobs[i].buf = base + int(offsets[i])
+        jobs[i].len = int(lengths[i])
+        jobs[i].adler = 1 if adlers is None else int(adlers[i]) & 0xffffffff
+        jobs[i].crc = 0 if crcs is None else int(crcs[i]) & 0xffffffff
+    _check(lib().zng_rocm_checksums_dev(which, C.byref(jobs), n, _dev_ptr(out2), _stream_ptr(stream)),
+           "zng_rocm_checksums_dev")
 
 
 def adler32_combine_dev(checks, lens, out, stream=None):
