@@ -57,7 +57,7 @@ constexpr int kCodeLit = 0, kCodeDist = 1, kCodeCl = 2;
 template <int RING>
 struct InflateLds {
     uint16_t lit[1 << kLitRoot];
-    uint16_t dist[1 << kDistRoot];
+    uint32_t dist[1 << kDistRoot];      // wide entries: code length | extra bits << 4 | base distance << 8 (wide_distance)
     uint16_t cl[1 << kClRoot];
     uint32_t cnt[3][16], first[3][16], offs[3][16], run[16];
     uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[32];
@@ -75,6 +75,18 @@ __device__ __forceinline__ void length_of(uint32_t k, uint32_t *base, uint32_t *
 __device__ __forceinline__ void distance_of(uint32_t k, uint32_t *base, uint32_t *extra) {   // k = symbol, 0..29
     if (k < 4) { *base = 1 + k; *extra = 0; }
     else { const uint32_t e = (k - 2) >> 1; *extra = e; *base = 1 + ((2 + (k & 1)) << e); }
+}
+
+// the distance table's decode-loop form: base and extra-bit count ride in the entry (the loop is scalar-issue bound and
+// the arithmetic of distance_of is 11 scalar instructions per match; 1 KiB more LDS per stream)
+constexpr uint32_t kLongWide = 0xfffffff0u, kBadWide = 0xffffffe1u;
+__device__ __forceinline__ uint32_t wide_distance(uint32_t e) {           // e: a 16-bit entry
+    if (e == kLongMark) return kLongWide;
+    const uint32_t sym = e >> 4;
+    if (sym > 29u) return kBadWide;                                           // 30, 31 (inftrees.c:48-49), no code
+    uint32_t b = 0, x = 0;
+    distance_of(sym, &b, &x);
+    return (e & 15u) | (x << 4) | (b << 8);
 }
 
 __device__ __forceinline__ void wave_sync() {            // LDS written by some lanes is read by others of the same wave
@@ -287,6 +299,17 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         }
     };
 
+    // the 16-bit distance entries the builder left in the first half of L.dist -> wide entries, through registers
+    auto widen_distances = [&]() {
+        uint32_t w[(1 << kDistRoot) / 64];
+#pragma unroll
+        for (int j = 0; j < (1 << kDistRoot) / 64; ++j) w[j] = wide_distance(reinterpret_cast<const uint16_t *>(L.dist)[lane + 64 * j]);
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < (1 << kDistRoot) / 64; ++j) L.dist[lane + 64 * j] = w[j];
+        wave_sync();
+    };
+
     // The control flow below is kept to single-exit loops with an error word (no jumps out of nested loops): every branch
     // here is wave-uniform, and anything else makes the compiler carry loop-exit conditions as lane masks through the
     // hot loop (the first version of this kernel executed 73 scalar instructions per symbol, most of them that).
@@ -345,7 +368,8 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             if (lane < 32) L.lens[288 + lane] = 5;
             wave_sync();
             build_code(L, kCodeLit, L.lens, 288, kLitRoot, L.lit, L.sorted_lit, lane);
-            build_code(L, kCodeDist, L.lens + 288, 32, kDistRoot, L.dist, L.sorted_dist, lane);
+            build_code(L, kCodeDist, L.lens + 288, 32, kDistRoot, reinterpret_cast<uint16_t *>(L.dist), L.sorted_dist, lane);
+            widen_distances();
         } else {
             // dynamic block header (inflate.c:814-917)
             if (cnt < 32) append();
@@ -404,10 +428,12 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             if (bit_pos() > 8ull * in_len) { msg = kMsgStarved; break; }
             if (uni(L.lens[256]) == 0) { msg = kMsgNoEob; break; }
             if (uni((uint32_t)build_code(L, kCodeLit, L.lens, (int)nlen, kLitRoot, L.lit, L.sorted_lit, lane))) { msg = kMsgLitLenSet; break; }
-            if (uni((uint32_t)build_code(L, kCodeDist, L.lens + nlen, (int)ndist, kDistRoot, L.dist, L.sorted_dist, lane))) {
+            if (uni((uint32_t)build_code(L, kCodeDist, L.lens + nlen, (int)ndist, kDistRoot, reinterpret_cast<uint16_t *>(L.dist),
+                                         L.sorted_dist, lane))) {
                 msg = kMsgDistSet;
                 break;
             }
+            widen_distances();
         }
 
         // ---- symbol loop: the decode AND store halves of inflate_fast (inffast_tpl.h:140-300) -----------------------
@@ -466,21 +492,16 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             }
             if (cnt < 32) append();
             uint32_t d = uni(L.dist[(uint32_t)hold & ((1u << kDistRoot) - 1u)]);
-            if (d == kLongMark) d = long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold);
-            const uint32_t dsym = d >> 4, dnb = d & 15u;
-            if (dsym > 29u) { msg = kMsgDistCode; break; }                            // 30, 31 (inftrees.c:48-49), no code
-            hold >>= dnb;
-            cnt -= dnb;
-            uint32_t dist;
-            if (dsym < 4u) {
-                dist = 1u + dsym;
-            } else {
-                const uint32_t xb = (dsym - 2u) >> 1;
-                dist = 1u + ((2u + (dsym & 1u)) << xb) + ((uint32_t)hold & ((1u << xb) - 1u));
-                hold >>= xb;
-                cnt -= xb;
+            if (d >= kBadWide) {
+                if (d == kLongWide) d = wide_distance(long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold));
+                if (d >= kBadWide) { msg = kMsgDistCode; break; }
             }
-            if (dist > op && dist - op > dict_len) { msg = kMsgTooFar; break; }       // inffast_tpl.h:203-210
+            const uint32_t dnb = d & 15u, dxb = (d >> 4) & 15u;
+            hold >>= dnb;
+            const uint32_t dist = (d >> 8) + ((uint32_t)hold & ((1u << dxb) - 1u));
+            hold >>= dxb;
+            cnt -= dnb + dxb;
+            if (dist > op + dict_len) { msg = kMsgTooFar; break; }                    // inffast_tpl.h:203-210
             service();
             if (msg != kMsgNone) break;
             if (len > out_cap - op) { msg = kMsgOutFull; break; }
