@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // Codes longer than the root get a kLong entry; the decode loop resolves those with the same comparison (they are the
 // rare symbols by construction).  Returns 0, or 1 for an invalid set.
 template <int RING>
-__device__ int build_code(InflateLds<RING> &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
+__device__ __forceinline__ int build_code(InflateLds<RING> &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
                           uint16_t *sorted, int lane) {
     uint32_t *cnt = L.cnt[which], *first = L.first[which], *offs = L.offs[which];
     if (lane < 16) cnt[lane] = 0;
@@ -209,7 +209,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     const uint32_t lead = (uint32_t)((uintptr_t)J.in & 3u);
     const ZR_GLOBAL uint32_t *const words = (const ZR_GLOBAL uint32_t *)(in - lead);
     const uint32_t total_words = (lead + in_len + 3u) >> 2;
-    auto fetch = [&](uint32_t base) -> uint32_t {
+    auto fetch = [&](uint32_t base) __attribute__((always_inline)) -> uint32_t {
         const uint32_t k = base + (uint32_t)lane;
         return k < total_words ? words[k] : 0u;
     };
@@ -217,7 +217,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     uint32_t wnext = 0;                                  // index of the next word to enter the bit buffer
     unsigned long long hold = 0;
     uint32_t cnt = 0;
-    auto append = [&]() {                                // cnt <= 32 on entry
+    auto append = [&]() __attribute__((always_inline)) {                                // cnt <= 32 on entry
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wnext - cbase));
         hold |= (unsigned long long)w << cnt;
         cnt += 32;
@@ -228,7 +228,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             nxt = fetch(cbase + 64);
         }
     };
-    auto seek = [&](uint32_t byte_off) {                 // restart the bit buffer at a byte of the stream
+    auto seek = [&](uint32_t byte_off) __attribute__((always_inline)) {                 // restart the bit buffer at a byte of the stream
         const uint32_t a = lead + byte_off;
         wnext = a >> 2;
         cbase = wnext;
@@ -240,7 +240,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         hold >>= 8 * (a & 3u);
         cnt -= 8 * (a & 3u);
     };
-    auto bit_pos = [&]() -> unsigned long long {         // stream bits consumed so far
+    auto bit_pos = [&]() __attribute__((always_inline)) -> unsigned long long {         // stream bits consumed so far
         return 32ull * wnext - 8ull * lead - cnt;
     };
     seek(0);
@@ -251,14 +251,14 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     // no LDS access, no EXEC juggling); the run goes to the ring in one ds_write when a match, a flush or the 64th
     // literal comes.  `op` already counts the waiting literals.
     uint32_t litbuf = 0, npend = 0;
-    auto dump = [&]() {
+    auto dump = [&]() __attribute__((always_inline)) {
         if (npend) {
             if ((uint32_t)lane < npend) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
             npend = 0;
         }
     };
     // ring -> HBM: everything below `limit` (all of it when `final`), in aligned 16-byte stores
-    auto flush = [&](uint32_t limit, bool final) {
+    auto flush = [&](uint32_t limit, bool final) __attribute__((always_inline)) {
         if (((a0 + flushed) & 15u) && flushed < limit) {
             uint32_t h = 16u - ((a0 + flushed) & 15u);
             if (h > limit - flushed) h = limit - flushed;
@@ -282,7 +282,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     // Everything that is not decoding happens when the literal run is written out, i.e. once per match or per 64
     // literals: the run goes to the ring (clipped at out_cap: a run may have decoded past it), a flush when one is due,
     // and the test that ends the decode of a truncated stream (the zero bits behind the input decode to something for ever).
-    auto service = [&]() {
+    auto service = [&]() __attribute__((always_inline)) {
         if (op > out_cap) {
             const uint32_t fit = npend - (op - out_cap);
             if ((uint32_t)lane < fit) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
@@ -300,7 +300,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     };
 
     // the 16-bit distance entries the builder left in the first half of L.dist -> wide entries, through registers
-    auto widen_distances = [&]() {
+    auto widen_distances = [&]() __attribute__((always_inline)) {
         uint32_t w[(1 << kDistRoot) / 64];
 #pragma unroll
         for (int j = 0; j < (1 << kDistRoot) / 64; ++j) w[j] = wide_distance(reinterpret_cast<const uint16_t *>(L.dist)[lane + 64 * j]);
@@ -310,6 +310,8 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         wave_sync();
     };
 
+    // (Every lambda above is always_inline: one that is called out of line gets its captures through the stack -- the
+    // whole bit-parse state would live in scratch memory.)
     // The control flow below is kept to single-exit loops with an error word (no jumps out of nested loops): every branch
     // here is wave-uniform, and anything else makes the compiler carry loop-exit conditions as lane masks through the
     // hot loop (the first version of this kernel executed 73 scalar instructions per symbol, most of them that).
