@@ -228,3 +228,52 @@ def test_mutated_streams_agree_with_the_oracle(inf):
         if (r[0], r[3]) != (ost, omsg) or (ost == 1 and (o != oout or r[2] != oused)):
             differ.append((s[:16].hex(), len(s), r[:1] + r[3:], (ost, omsg)))
     assert not differ, differ[:5]
+
+
+def test_two_batches_on_two_streams_from_two_host_threads(inf):
+    """independent callers on independent HIP streams (zlib-ng.h.in:157-159; test/test_deflate_concurrency.cc:73-170):
+    the job tables of zng_rocm_inflate_streams_dev are scratch of the caller's stream, so two host threads decoding
+    different batches at the same time must each get their own plaintext, over and over"""
+    import threading
+    torch = torch_mod()
+    zr = product()
+    each, n = 128 << 10, 128
+    plains, batches = [], []
+    for k in range(2):
+        data = synth.silesia_like(n * each, seed=700 + k, seg_bytes=256 << 10)
+        blobs = [_raw(data[i * each:(i + 1) * each].tobytes(), 1 + 5 * k) for i in range(n)]
+        offs, pos = [], 0
+        for b in blobs:
+            offs.append(pos)
+            pos += len(b) + 5
+        packed = np.zeros(pos + 16, dtype=np.uint8)
+        for o, b in zip(offs, blobs):
+            packed[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        dst = torch.zeros(n * each + 16, dtype=torch.uint8, device="cuda")
+        batches.append(inf.InflateDevBatch(torch.from_numpy(packed).cuda(), offs, [len(b) for b in blobs], dst,
+                                           [i * each for i in range(n)], [each] * n))
+        plains.append(torch.from_numpy(data).cuda())
+    errors = []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            for it in range(6):
+                batches[k].dst.zero_()
+                torch.cuda.current_stream().synchronize()
+                batches[k].run(stream=s)
+                s.synchronize()
+                r = batches[k].results.cpu()
+                if not bool((r[:, 2] == 1).all()) or not torch.equal(batches[k].dst[:n * each], plains[k]):
+                    errors.append((k, it))
+                    return
+            zr.rocm.lib().zng_rocm_stream_release(s.cuda_stream)
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
