@@ -368,7 +368,7 @@ int  zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthread
 
 /* Many independent raw deflate streams that are ALREADY in device memory, decoded entirely on the device: one wavefront
  * per stream runs slot `inflate_fast` (inffast_tpl.h:53-318) and the block decoding around it (inflate.c:735-917,
- * inftrees.c:32-297) -- Huffman decode and copies -- with the last 8 KiB of output in an LDS ring (inflate's sliding
+ * inftrees.c:32-297) -- Huffman decode and copies -- with the last 4 KiB of output in an LDS ring (inflate's sliding
  * window, inflate.c:325-378).  The inverse of zng_rocm_deflate_quick_dev for the reference's many-stream model
  * (test/pigz/CMakeLists.txt:123-200): nothing crosses PCIe.  `dict_len` bytes of history (a dictionary,
  * inflateSetDictionary on a raw stream inflate.c:1214-1261, or the previous window) must sit directly in front of `out`.

@@ -609,8 +609,12 @@ int zng_rocm_inflate_streams_dev(const zng_rocm_inflate_dev_job *jobs, size_t nj
     }
     ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
     if (int rc = host_tables_release(ws, st)) return rc;
-    int ring = 4096;                 // measured: 4 KiB -> 17 streams per CU; 8 KiB (12 per CU) is 25 % slower on both corpora
-    if (const char *r = getenv("ZNG_ROCM_INFLATE_RING")) ring = atoi(r);
+    // ring size: 4 KiB -> 16 streams per CU; 8 KiB (11 per CU) measured 25 % slower on both corpora.  The other
+    // instantiations stay for measurements (ZNG_ROCM_INFLATE_RING, read once).
+    static const int ring = [] {
+        const char *r = getenv("ZNG_ROCM_INFLATE_RING");
+        return r ? atoi(r) : 4096;
+    }();
     if (ring == 8192) ZR_LAUNCH_TRACED(inflate_streams_kernel<8192>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
     else if (ring == 16384) ZR_LAUNCH_TRACED(inflate_streams_kernel<16384>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
     else if (ring == 32768) ZR_LAUNCH_TRACED(inflate_streams_kernel<32768>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
