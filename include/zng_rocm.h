@@ -387,6 +387,24 @@ int  zng_rocm_inflate_streams_dev(const zng_rocm_inflate_dev_job *jobs, size_t n
 /* the reference's strm->msg text for a message id of d_results ("" for 0 / unknown ids) */
 const char *zng_rocm_inflate_message(uint32_t id);
 
+/* zlib (format 1) / gzip (format 2) / raw (format 0) framing for MANY device-resident streams -- compress2 / uncompress2
+ * (compress.c:31-69, uncompr.c:25-76) in the shape of the many-stream model, every step on the device, asynchronous on
+ * `stream`:
+ *   compress: the level-1 class per stream + (gzip) the CRC-32 of every plaintext in one pass + one kernel that writes
+ *   every header and trailer.  Both wrappers are 12 bytes long so that the block starts 4-byte aligned: gzip declares an
+ *   empty FEXTRA field, zlib puts two empty stored blocks behind its 2-byte header.  Per job: out 4-byte aligned,
+ *   out_cap >= zng_rocm_compress_streams_bound(in_len, format), no dictionary / flags for a wrapped stream.
+ *   d_results: 2 words per job {total bytes written, check value (Adler-32; gzip: CRC-32)}.
+ *   uncompress: every header parsed on the device (inflate.c:509-555, :556-700 incl. FHCRC), zng_rocm_inflate_streams_dev's
+ *   kernel, the check values of all outputs in one many-message pass whose descriptors are filled on the device, every
+ *   trailer compared (inflate.c:1105-1147).  d_results: 4 words per job as zng_rocm_inflate_streams_dev, bytes consumed
+ *   counting header and trailer; message ids include "incorrect header check", "unknown compression method", "invalid
+ *   window size", "header crc mismatch", "need dictionary", "incorrect data check", "incorrect length check". */
+size_t zng_rocm_compress_streams_bound(size_t source_len, int format);
+int  zng_rocm_compress_streams_dev(int format, const zng_rocm_stream_job *jobs, size_t njobs, uint32_t *d_results, void *stream);
+int  zng_rocm_uncompress_streams_dev(int format, const zng_rocm_inflate_dev_job *jobs, size_t njobs, uint32_t *d_results,
+                                     void *stream);
+
 /* ONE raw stream with its host decode spread over `nthreads` threads (zng_rocm_inflate_tokens_decode_threads) and one
  * device pass; same results and status as zng_rocm_inflate_raw_window, which it falls back to for streams that
  * offer no block boundary to cut at or turn out irregular.  Synchronous. */

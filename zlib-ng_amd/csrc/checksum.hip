@@ -111,6 +111,28 @@ int launch_checksum(bool do_adler, bool do_crc, uint32_t adler, uint32_t crc, co
     return ZNG_ROCM_OK;
 }
 
+int launch_checksum_batch_device(bool do_adler, bool do_crc, const StreamArgs *d_messages, const FinalArgs *d_finals,
+                                 Partial *d_part, size_t rows, uint32_t *d_out2, hipStream_t stream) {
+    Context *c = ctx();
+    if (!c) return ZNG_ROCM_ENODEV;
+    if (!rows) return ZNG_ROCM_OK;
+    for (size_t first = 0; first < rows; first += 32768) {
+        const size_t n = rows - first < 32768 ? rows - first : 32768;
+        dim3 grid(1, (unsigned)n), block(kWgThreads);
+        if (do_adler && do_crc)
+            ZR_LAUNCH_TRACED((stream_kernel_batch<true, true>), grid, block, stream, d_messages + first, c->tables, d_part + first);
+        else if (do_adler)
+            ZR_LAUNCH_TRACED((stream_kernel_batch<true, false>), grid, block, stream, d_messages + first, c->tables, d_part + first);
+        else
+            ZR_LAUNCH_TRACED((stream_kernel_batch<false, true>), grid, block, stream, d_messages + first, c->tables, d_part + first);
+        ZR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(finalize_kernel_batch, dim3((unsigned)n), dim3(256), 0, stream, d_finals + first, c->tables,
+                           d_part + first, d_out2 + 2 * first);
+        ZR_HIP(hipGetLastError());
+    }
+    return ZNG_ROCM_OK;
+}
+
 }  // namespace zr
 
 using namespace zr;

@@ -66,6 +66,9 @@ enum ScratchSlot {
     kScrCheckMessages,      // device: StreamArgs[] | FinalArgs[] of zng_rocm_checksums_dev
     kScrCheckMessagesHost,  // pinned
     kScrCheckPartials,      // device: Partial[] (messages x workgroups per message)
+    kScrFrameWords,         // device: per-stream words of the many-stream framing entry points (framing_dev.hip)
+    kScrFrameJobs,          // device: FrameJob[]
+    kScrFrameJobsHost,      // pinned
     kScrCount
 };
 

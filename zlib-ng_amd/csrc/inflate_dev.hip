@@ -25,22 +25,10 @@
 
 #include "context.h"
 #include "deflate_dev.h"
+#include "inflate_dev.h"
 
 namespace zr {
 
-struct InflateJobDev {
-    const uint8_t *in;
-    uint8_t       *out;
-    uint64_t       in_len;
-    uint64_t       out_cap;
-    uint32_t       dict_len;
-    uint32_t       flags;
-};
-
-enum InflateMsg : uint32_t {
-    kMsgNone = 0, kMsgBlockType, kMsgStoredLen, kMsgTooMany, kMsgCodeLengthsSet, kMsgBitRepeat, kMsgNoEob,
-    kMsgLitLenSet, kMsgDistSet, kMsgLitLenCode, kMsgDistCode, kMsgTooFar, kMsgStarved, kMsgOutFull, kMsgCount
-};
 
 // Table entry, 16 bits: code length in bits 0-3, SYMBOL in bits 4-15 (literal/length 0..287, distance 0..31, code-length
 // symbol 0..18).  Base values and extra-bit counts are arithmetic in the symbol (length_of / distance_of), so nothing
@@ -567,6 +555,22 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     }
 }
 
+int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, hipStream_t st) {
+    if (!njobs) return ZNG_ROCM_OK;
+    // ring size: 4 KiB -> 16 streams per CU; 8 KiB (11 per CU) measured 25 % slower on both corpora.  The other
+    // instantiations stay for measurements (ZNG_ROCM_INFLATE_RING, read once).
+    static const int ring = [] {
+        const char *r = getenv("ZNG_ROCM_INFLATE_RING");
+        return r ? atoi(r) : 4096;
+    }();
+    if (ring == 8192) ZR_LAUNCH_TRACED(inflate_streams_kernel<8192>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else if (ring == 16384) ZR_LAUNCH_TRACED(inflate_streams_kernel<16384>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else if (ring == 32768) ZR_LAUNCH_TRACED(inflate_streams_kernel<32768>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    else ZR_LAUNCH_TRACED(inflate_streams_kernel<4096>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
 }  // namespace zr
 
 using namespace zr;
@@ -578,7 +582,9 @@ const char *zng_rocm_inflate_message(uint32_t id) {
         "", "invalid block type", "invalid stored block lengths", "too many length or distance symbols",
         "invalid code lengths set", "invalid bit length repeat", "invalid code -- missing end-of-block",
         "invalid literal/lengths set", "invalid distances set", "invalid literal/length code", "invalid distance code",
-        "invalid distance too far back", "input ended before the final block", "output buffer too small"};
+        "invalid distance too far back", "input ended before the final block", "output buffer too small",
+        "incorrect header check", "unknown compression method", "invalid window size", "header crc mismatch",
+        "need dictionary", "incorrect data check", "incorrect length check"};
     return id < kMsgCount ? text[id] : "";
 }
 
@@ -609,17 +615,7 @@ int zng_rocm_inflate_streams_dev(const zng_rocm_inflate_dev_job *jobs, size_t nj
     }
     ZR_HIP(hipMemcpyAsync(d_jobs, h_jobs, njobs * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
     if (int rc = host_tables_release(ws, st)) return rc;
-    // ring size: 4 KiB -> 16 streams per CU; 8 KiB (11 per CU) measured 25 % slower on both corpora.  The other
-    // instantiations stay for measurements (ZNG_ROCM_INFLATE_RING, read once).
-    static const int ring = [] {
-        const char *r = getenv("ZNG_ROCM_INFLATE_RING");
-        return r ? atoi(r) : 4096;
-    }();
-    if (ring == 8192) ZR_LAUNCH_TRACED(inflate_streams_kernel<8192>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else if (ring == 16384) ZR_LAUNCH_TRACED(inflate_streams_kernel<16384>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else if (ring == 32768) ZR_LAUNCH_TRACED(inflate_streams_kernel<32768>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else ZR_LAUNCH_TRACED(inflate_streams_kernel<4096>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    ZR_HIP(hipGetLastError());
+    if (int rc = launch_inflate_streams_device(d_jobs, njobs, d_results, st)) return rc;
     return ZNG_ROCM_OK;
 }
 

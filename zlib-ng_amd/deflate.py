@@ -72,6 +72,42 @@ class QuickBatch:
         return self.dst[o:o + clen].cpu().numpy().tobytes()
 
 
+class WrappedBatch:
+    """zng_rocm_compress_streams_dev: many streams, level-1 class, with their zlib (fmt 1) / gzip (fmt 2) wrapper written on
+    the device.  Layout as QuickBatch; results: int32 CUDA tensor [n, 2] = {total bytes, check value}."""
+
+    def __init__(self, src, in_off, in_len, fmt):
+        import torch
+        rocm._need_init()
+        self.src, self.fmt = src, fmt
+        self.n = len(in_len)
+        self.bounds = [(rocm.lib().zng_rocm_compress_streams_bound(int(v), fmt) + 15) & ~15 for v in in_len]
+        self.out_off, total = [], 0
+        for b in self.bounds:
+            self.out_off.append(total)
+            total += b
+        self.dst = torch.zeros(max(total, 16), dtype=torch.uint8, device=src.device)
+        self.results = torch.zeros((self.n, 2), dtype=torch.int32, device=src.device)
+        self.jobs = (StreamJob * self.n)()
+        bi, bo = src.data_ptr(), self.dst.data_ptr()
+        for i in range(self.n):
+            self.jobs[i].in_ptr = bi + int(in_off[i])
+            self.jobs[i].out_ptr = bo + self.out_off[i]
+            self.jobs[i].in_len = int(in_len[i])
+            self.jobs[i].out_cap = self.bounds[i]
+            self.jobs[i].dict_len = 0
+            self.jobs[i].flags = 0
+
+    def run(self, stream=None):
+        rocm._check(rocm.lib().zng_rocm_compress_streams_dev(self.fmt, C.byref(self.jobs), self.n, rocm._dev_ptr(self.results),
+                                                             rocm._stream_ptr(stream)), "zng_rocm_compress_streams_dev")
+
+    def compressed(self, i, results_host=None):
+        res = self.results.cpu() if results_host is None else results_host
+        o = self.out_off[i]
+        return self.dst[o:o + int(res[i, 0])].cpu().numpy().tobytes()
+
+
 def deflate_bound(n):
     return rocm.lib().zng_rocm_deflate_bound(n)
 

@@ -202,6 +202,12 @@ class InflateDevBatch:
         rocm._check(rocm.lib().zng_rocm_inflate_streams_dev(C.byref(self.jobs), self.n, rocm._dev_ptr(self.results),
                                                             rocm._stream_ptr(stream)), "zng_rocm_inflate_streams_dev")
 
+    def run_wrapped(self, fmt, stream=None):
+        """the same streams with their zlib (1) / gzip (2) wrapper: header parse, inflate, check values of the outputs and
+        trailer comparison, all on the device (zng_rocm_uncompress_streams_dev)"""
+        rocm._check(rocm.lib().zng_rocm_uncompress_streams_dev(fmt, C.byref(self.jobs), self.n, rocm._dev_ptr(self.results),
+                                                               rocm._stream_ptr(stream)), "zng_rocm_uncompress_streams_dev")
+
     def rows(self):
         """[(status, out_len, in_used, message)] (synchronises)"""
         r = self.results.cpu().tolist()

@@ -97,6 +97,9 @@ _PROTOS = {
                                                C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_int]),
     "zng_rocm_inflate_many": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
     "zng_rocm_inflate_streams_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_compress_streams_bound": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "zng_rocm_compress_streams_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zng_rocm_uncompress_streams_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zng_rocm_inflate_message": (C.c_char_p, [C.c_uint32]),
     "zng_rocm_inflate_tokens_free": (None, [C.c_void_p]),
     "zng_rocm_inflate_resolve_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
