@@ -439,6 +439,25 @@ def main():
                       "kernel_frac_of_8TBps": round(nstreams * each / 1e9 / (ck_kernel[2] / 1e3) / 8000, 3)},
             "both": {"ms": round(ck_ms[3], 3), "kernel_ms": round(ck_kernel[3], 3),
                      "kernel_frac_of_8TBps": round(nstreams * each / 1e9 / (ck_kernel[3] / 1e3) / 8000, 3)}}
+        # the same streams as gzip members, framed and verified on the device (framing_dev.hip)
+        wb = dfl.WrappedBatch(src, [i * each for i in range(nstreams)], [each] * nstreams, 2)
+        gz_ms = gpu_time_ms(wb.run, 3, torch)
+        wres = wb.results.cpu()
+        totals = [int(v) for v in wres[:, 0]]
+        gplain = torch.empty(nstreams * each + 64, dtype=torch.uint8, device="cuda")
+        gb = inf.InflateDevBatch(wb.dst, wb.out_off, totals, gplain, [i * each for i in range(nstreams)], [each] * nstreams)
+        gun_ms = gpu_time_ms(lambda: gb.run_wrapped(2), 3, torch)
+        grows = gb.results.cpu()
+        import gzip as _gzip
+        report["cfg5_gzip"] = {
+            "workload": "the %d streams as gzip members: level-1 class + CRC-32 of every plaintext + headers / trailers "
+                        "(zng_rocm_compress_streams_dev), then header parse + inflate + CRC-32 of every output + trailer "
+                        "comparison (zng_rocm_uncompress_streams_dev); nothing on the host in between" % nstreams,
+            "compress_ms": round(gz_ms, 2), "compress_in_GBps": round(nstreams * each / 1e9 / (gz_ms / 1e3), 2),
+            "uncompress_ms": round(gun_ms, 2), "uncompress_out_GBps": round(nstreams * each / 1e9 / (gun_ms / 1e3), 2),
+            "bit_exact": bool((grows[:, 2] == 1).all()) and grows[:, 1].tolist() == totals and torch.equal(gplain[:nstreams * each], src),
+            "python_gzip_reads_member_0": _gzip.decompress(wb.compressed(0, wres)) == host[:each].tobytes()}
+        del wb, gb, gplain
         # the same many-stream job at pigz's default level: zng_rocm_deflate_streams_dev (chain walk + dynamic Huffman)
         sb = dfl.StreamsBatch(src, [i * each for i in range(nstreams)], [each] * nstreams)
         t0 = time.perf_counter()
