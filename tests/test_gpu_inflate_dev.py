@@ -277,3 +277,36 @@ def test_two_batches_on_two_streams_from_two_host_threads(inf):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_fifty_thousand_tiny_streams(inf):
+    """a job table far larger than the machine: 50000 streams of 30..300 bytes in one launch (plus the zlib framing path
+    over the same streams), every row checked"""
+    torch = torch_mod()
+    rng = np.random.default_rng(5)
+    n = 50000
+    words = [b"alpha", b"beta", b"gamma", b"delta", b" ", b"\n", b"0123456789", b"zzzzzzzz"]
+    plains = [b"".join(words[int(k)] for k in rng.integers(0, len(words), size=int(rng.integers(5, 40)))) for _ in range(n)]
+    blobs = [zlib.compress(p, 6) for p in plains]
+    offs, pos = [], 0
+    for b in blobs:
+        offs.append(pos)
+        pos += len(b)
+    packed = np.frombuffer(b"".join(blobs) + b"\0" * 64, dtype=np.uint8).copy()
+    out_off, opos = [], 0
+    for p in plains:
+        out_off.append(opos)
+        opos += len(p)
+    dst = torch.zeros(opos + 64, dtype=torch.uint8, device="cuda")
+    src = torch.from_numpy(packed).cuda()
+    raw = inf.InflateDevBatch(src, [o + 2 for o in offs], [len(b) - 6 for b in blobs], dst, out_off, [len(p) for p in plains])
+    raw.run()
+    r = raw.results.cpu()
+    assert (r[:, 2] == 1).all() and r[:, 0].tolist() == [len(p) for p in plains] and r[:, 1].tolist() == [len(b) - 6 for b in blobs]
+    assert dst[:opos].cpu().numpy().tobytes() == b"".join(plains)
+    dst.zero_()
+    wrapped = inf.InflateDevBatch(src, offs, [len(b) for b in blobs], dst, out_off, [len(p) for p in plains])
+    wrapped.run_wrapped(1)
+    r = wrapped.results.cpu()
+    assert (r[:, 2] == 1).all() and (r[:, 3] == 0).all() and r[:, 1].tolist() == [len(b) for b in blobs]
+    assert dst[:opos].cpu().numpy().tobytes() == b"".join(plains)
