@@ -74,15 +74,15 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 
     const Run runs[] = {
-        {"adler32 V=4096", launcher<true, false, 4096, false>, false, true, false},
-        {"adler32 V=4096+8192 wave priorities", launcher<true, false, 4096 + 8192, false>, false, true, false},
-        {"crc32 V=0 (round-1 form)", launcher<false, true, 0, false>, true, false, false},
-        {"crc32 V=7362", launcher<false, true, 7362, false>, true, false, false},
-        {"crc32 V=7362+8192 wave priorities", launcher<false, true, 7362 + 8192, false>, true, false, false},
-        {"fused V=7362", launcher<true, true, 7362, false>, true, true, false},
-        {"fused V=7362+8192 wave priorities", launcher<true, true, 7362 + 8192, false>, true, true, false},
-        {"fused V=7362 PROFILE", launcher<true, true, 7362, true>, true, true, true},
-        {"fused V=7362+8192 PROFILE", launcher<true, true, 7362 + 8192, true>, true, true, true},
+        {"adler32 UNROLL 4 (product)", launcher<true, false, 7362, false>, false, true, false},
+        {"adler32 UNROLL 2", launcher<true, false, 7362, false, 2>, false, true, false},
+        {"adler32 UNROLL 1", launcher<true, false, 7362, false, 1>, false, true, false},
+        {"crc32 UNROLL 4 (product)", launcher<false, true, 7362, false>, true, false, false},
+        {"crc32 UNROLL 2", launcher<false, true, 7362, false, 2>, true, false, false},
+        {"crc32 UNROLL 1", launcher<false, true, 7362, false, 1>, true, false, false},
+        {"fused UNROLL 4 (product)", launcher<true, true, 7362, false>, true, true, false},
+        {"fused UNROLL 2", launcher<true, true, 7362, false, 2>, true, true, false},
+        {"fused UNROLL 1", launcher<true, true, 7362, false, 1>, true, true, false},
     };
 
     const int WARM = 300, REPS = 200;

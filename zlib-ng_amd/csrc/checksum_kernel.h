@@ -672,7 +672,14 @@ __device__ __forceinline__ void stream_body(const StreamArgs &args, const Device
     stamp(5);
 }
 
-template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false, int UNROLL = 4>
+// UNROLL = rows per register buffer.  For the read-only passes one row per buffer (two rows in flight per lane, 32 per
+// CU) measured best at every size (tools/micro/crc_phases, profiles/r02_crc_phases.md run 8: fused 1 GiB 0.798 -> 0.830 of
+// peak, 256 MiB 0.69 -> 0.79, 64 MiB 0.53 -> 0.59 against four rows): a CU accepts only so many loads in flight, and
+// deeper buffers only queue.  The copying passes (fold_copy: a store stream beside the load stream) keep four: with
+// one they fall from 0.72 to 0.63 of peak at 1 GiB.
+constexpr int kRowsPerBuffer = 1, kRowsPerBufferCopy = 4;
+template <bool DO_ADLER, bool DO_CRC, bool COPY, int V = kCrcVariant, bool PROFILE = false,
+          int UNROLL = COPY ? kRowsPerBufferCopy : kRowsPerBuffer>
 __global__ __launch_bounds__(kWgThreads)
 void stream_kernel(StreamArgs args, const DeviceTables *__restrict__ tabs, Partial *__restrict__ partials) {
     stream_body<DO_ADLER, DO_CRC, COPY, V, PROFILE, UNROLL>(args, tabs, partials, gridDim.x, blockIdx.x);
@@ -683,7 +690,7 @@ template <bool DO_ADLER, bool DO_CRC, int V = kCrcVariant>
 __global__ __launch_bounds__(kWgThreads)
 void stream_kernel_batch(const StreamArgs *__restrict__ messages, const DeviceTables *__restrict__ tabs,
                          Partial *__restrict__ partials) {
-    stream_body<DO_ADLER, DO_CRC, false, V, false, 4>(messages[blockIdx.y], tabs, partials + (size_t)blockIdx.y * gridDim.x,
+    stream_body<DO_ADLER, DO_CRC, false, V, false, kRowsPerBuffer>(messages[blockIdx.y], tabs, partials + (size_t)blockIdx.y * gridDim.x,
                                                       gridDim.x, blockIdx.x);
 }
 
