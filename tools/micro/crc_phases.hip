@@ -74,15 +74,9 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 
     const Run runs[] = {
-        {"adler32 UNROLL 4 (product)", launcher<true, false, 7362, false>, false, true, false},
-        {"adler32 UNROLL 2", launcher<true, false, 7362, false, 2>, false, true, false},
-        {"adler32 UNROLL 1", launcher<true, false, 7362, false, 1>, false, true, false},
-        {"crc32 UNROLL 4 (product)", launcher<false, true, 7362, false>, true, false, false},
-        {"crc32 UNROLL 2", launcher<false, true, 7362, false, 2>, true, false, false},
-        {"crc32 UNROLL 1", launcher<false, true, 7362, false, 1>, true, false, false},
-        {"fused UNROLL 4 (product)", launcher<true, true, 7362, false>, true, true, false},
-        {"fused UNROLL 2", launcher<true, true, 7362, false, 2>, true, true, false},
-        {"fused UNROLL 1", launcher<true, true, 7362, false, 1>, true, true, false},
+        {"adler32 (product: one row per buffer)", launcher<true, false, 7362, false, 1>, false, true, false},
+        {"crc32 (product)", launcher<false, true, 7362, false, 1>, true, false, false},
+        {"fused (product)", launcher<true, true, 7362, false, 1>, true, true, false},
     };
 
     const int WARM = 300, REPS = 200;

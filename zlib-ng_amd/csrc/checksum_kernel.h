@@ -41,7 +41,11 @@ __device__ __forceinline__ void st_stream(uint8_t *p, uint4 v) {
 
 // streaming (read-once) 16-byte load: non-temporal hint, the data is never re-read
 __device__ __forceinline__ uint4 ld_stream(const uint8_t *p) {
+#ifdef ZR_EXPERIMENT_PLAIN_LOADS                     // tools/micro only: the same pass without the non-temporal hint
+    const u32x4_t v = *reinterpret_cast<const u32x4_t *>(p);
+#else
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+#endif
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
