@@ -74,9 +74,19 @@ int main(int argc, char **argv) {
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 
     const Run runs[] = {
-        {"adler32 (product: one row per buffer)", launcher<true, false, 7362, false, 1>, false, true, false},
-        {"crc32 (product)", launcher<false, true, 7362, false, 1>, true, false, false},
-        {"fused (product)", launcher<true, true, 7362, false, 1>, true, true, false},
+        {"adler32 (product)", launcher<true, false, kCrcVariant, false, kRowsPerBuffer>, false, true, false},
+        {"adler32, four rows per buffer", launcher<true, false, kCrcVariant, false, 4>, false, true, false},
+        {"crc32 V=0, four rows (round-1 form)", launcher<false, true, 0, false, 4>, true, false, false},
+        {"crc32 V=194 built tables, lds barrier, x32 fold", launcher<false, true, 194, false, 4>, true, false, false},
+        {"crc32 V=1218 + byte-addressed image", launcher<false, true, 1218, false, 4>, true, false, false},
+        {"crc32 V=3266 + direct image", launcher<false, true, 3266, false, 4>, true, false, false},
+        {"crc32 V=7362 + two-level epilogue", launcher<false, true, 7362, false, 4>, true, false, false},
+        {"crc32 (product: V=7362, one row per buffer)", launcher<false, true, kCrcVariant, false, kRowsPerBuffer>, true, false, false},
+        {"fused V=0, four rows (round-1 form)", launcher<true, true, 0, false, 4>, true, true, false},
+        {"fused V=7362, four rows", launcher<true, true, 7362, false, 4>, true, true, false},
+        {"fused (product)", launcher<true, true, kCrcVariant, false, kRowsPerBuffer>, true, true, false},
+        {"crc32 (product) PROFILE", launcher<false, true, kCrcVariant, true, kRowsPerBuffer>, true, false, true},
+        {"fused (product) PROFILE", launcher<true, true, kCrcVariant, true, kRowsPerBuffer>, true, true, true},
     };
 
     const int WARM = 300, REPS = 200;
