@@ -200,9 +200,10 @@ int zng_rocm_checksums_dev(int which, const zng_rocm_check_job *jobs, size_t njo
         const size_t u = (size_t)((jobs[i].len + 15 + kUnitBytes) / kUnitBytes);
         if (u > max_units) max_units = u;
     }
-    // workgroups per message: one up to 1024 units (16 MiB), then as many as keep every workgroup at <= 1024 units
+    // workgroups per message: one up to 1024 units (16 MiB), more above, at most 16
     size_t G = (max_units + 1023) / 1024;
-    if (G > (size_t)c->cus) G = (size_t)c->cus;
+    if (G > 16) G = 16;             // every message of the call gets G workgroups: one very long message among many
+                                    //   short ones must not multiply the grid (it belongs to zng_rocm_*_dev anyway)
     constexpr size_t kRows = 32768;                     // grid.y per launch
     const size_t per = sizeof(StreamArgs) + sizeof(FinalArgs);
     const size_t rows_max = njobs < kRows ? njobs : kRows;
