@@ -372,7 +372,8 @@ int  zng_rocm_inflate_many(zng_rocm_inflate_job *jobs, size_t njobs, int nthread
  * window, inflate.c:325-378).  The inverse of zng_rocm_deflate_quick_dev for the reference's many-stream model
  * (test/pigz/CMakeLists.txt:123-200): nothing crosses PCIe.  `dict_len` bytes of history (a dictionary,
  * inflateSetDictionary on a raw stream inflate.c:1214-1261, or the previous window) must sit directly in front of `out`.
- * Asynchronous on `stream`; jobs is a host array (copied before the call returns).
+ * Asynchronous on `stream`; jobs is a host array (copied before the call returns).  The compressed words are fetched as
+ * aligned dwords: up to 3 bytes on either side of [in, in + in_len) inside the same 4-byte words are read (never used).
  * d_results: 4 uint32 per job: {bytes produced, input bytes consumed, status as int32 (1 = Z_STREAM_END, -3 = Z_DATA_ERROR,
  * -5 = Z_BUF_ERROR: input ended early or out_cap too small), message id for zng_rocm_inflate_message}. */
 typedef struct zng_rocm_inflate_dev_job {
