@@ -14,7 +14,9 @@ And the two single-stream members of the metric, `deflate_lvl6` (configs[3]) and
 stream per GPU (a single stream does not shard: replicas at N > 1).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, the driver's form)
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks (self_launch(): a child
+`torch.distributed.run`, started before this process has imported torch or touched HIP) and relays rank 0's line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -441,11 +443,30 @@ def emit(line):
 _REAL_STDOUT = 1
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` (N > 1) outside any launcher: start the N ranks as ONE child process tree, one rank per
+    GPU -- the many-stream model of the reference (test/pigz/CMakeLists.txt:123-200: independent workers, one result
+    table).  Runs before this process has imported torch or made any HIP call (a process that has initialised the GPU
+    must never exec or fork into another GPU program); the parent only waits, the child's stdout (rank 0's ONE JSON
+    line) is inherited, the exit code is the launcher's."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     global _REAL_STDOUT
-    sys.stdout.flush()
-    _REAL_STDOUT = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -458,17 +479,30 @@ def main():
                          "printed as the line")
     ap.add_argument("--streams", type=int, default=4096)
     ap.add_argument("--stream-steps", type=int, default=0, help="timed steps of the streams leg (0 = min(steps, 6))")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="every rank prints {rank, world, local_rank} as one JSON line and exits: exercises the launcher "
+                         "without a GPU (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))       # nothing above this line imports torch or touches HIP
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.launch_only:
+        print(json.dumps({"launch_only": True, "rank": rank, "world": world, "local_rank": local_rank,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        sys.exit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     # ZNG_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- lets the N>1 control flow be
     # rehearsed on a one-GPU box (RCCL refuses two ranks on one device); numbers from it mean nothing.
     rehearse = os.environ.get("ZNG_BENCH_REHEARSE") == "1"
