@@ -103,30 +103,51 @@ def main():
             # between kernels (and at a lower clock: the rows then read 1-3 us slower than tools/micro/crc_phases)
             import ctypes as C
             L = zr.lib()
-            p_in, p_out, p_dst = C.c_void_p(big.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(dst.data_ptr())
+            p_out = C.c_void_p(out.data_ptr())
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for name, fn, traffic in (
-                    ("adler32", lambda: L.zng_rocm_adler32_dev(1, p_in, n, p_out, st), 1),
-                    ("crc32", lambda: L.zng_rocm_crc32_dev(0, p_in, n, p_out, st), 1),
-                    ("adler32+crc32 fused", lambda: L.zng_rocm_adler32_crc32_dev(1, 0, p_in, n, p_out, st), 1),
-                    ("fold_copy (adler+crc, 2N traffic)", lambda: L.zng_rocm_fold_copy_dev(3, 1, 0, p_dst, p_in, n, p_out, st), 2)):
-                # three passes of {settle, 50 traced launches}; the row is the best pass (DVFS noise between passes is
-                # +-1.5 us at 64 MiB, far more than the spread inside one pass)
-                passes = []
-                for _ in range(3):
-                    for _ in range(max(200, 1000 * 64 // mib)):    # clocks settle
-                        fn()
-                    torch.cuda.synchronize()
-                    zr.trace_begin(50)
-                    for _ in range(50):
-                        fn()
-                    passes.append(statistics.mean(zr.trace_end(50)))
-                ms = min(passes)
-                step = gpu_time_ms(fn, 10, torch)
-                row[name] = {"kernel_ms": round(ms, 4), "algorithmic_GBps": round(traffic * n / 1e9 / (ms / 1e3), 1),
-                             "frac_of_8TBps": round(traffic * n / 1e9 / (ms / 1e3) / 8000, 3),
-                             "kernel_ms_passes": [round(x, 4) for x in passes],
-                             "step_ms_incl_finalize": round(step, 4)}
+            # Infinity Cache control (MI355X_MICROARCH.md, Infinity Cache: a line stays resident while everything touched
+            # between two of its uses fits in ~256 MiB): `rotated` walks K distinct n-byte slices of the big buffer, so
+            # that (K - 1) * n * traffic >= 320 MiB pass between two reads of a line -- those rows are HBM fractions.
+            # `same_buffer` re-reads one slice (at 64 and 256 MiB that is partly an Infinity Cache figure) and is kept
+            # beside it.  Each figure: median over 5 passes of {settle, 50 traced launches}, with min and max.
+            k_rot = max(1, min((max(sizes) << 20) // n, -(-320 // mib) + 1))
+            def ptrs(k):
+                return C.c_void_p(big.data_ptr() + k * n), C.c_void_p(dst.data_ptr() + k * n)
+            slices = [ptrs(k) for k in range(k_rot)]
+            row["rotation"] = {"slices": k_rot, "MiB_between_two_reads_of_a_line": (k_rot - 1) * mib}
+            for name, call, traffic in (
+                    ("adler32", lambda a, d: L.zng_rocm_adler32_dev(1, a, n, p_out, st), 1),
+                    ("crc32", lambda a, d: L.zng_rocm_crc32_dev(0, a, n, p_out, st), 1),
+                    ("adler32+crc32 fused", lambda a, d: L.zng_rocm_adler32_crc32_dev(1, 0, a, n, p_out, st), 1),
+                    ("fold_copy (adler+crc, 2N traffic)", lambda a, d: L.zng_rocm_fold_copy_dev(3, 1, 0, d, a, n, p_out, st), 2)):
+                row[name] = {}
+                for mode, nsl in (("rotated", k_rot), ("same_buffer", 1)):
+                    if mode == "same_buffer" and k_rot == 1:
+                        row[name][mode] = "= rotated (one slice is already past the Infinity Cache)"
+                        continue
+                    state = {"i": 0}
+                    def fn():
+                        a, d = slices[state["i"] % nsl]
+                        state["i"] += 1
+                        call(a, d)
+                    passes = []
+                    for _ in range(5):
+                        for _ in range(max(200, 1000 * 64 // mib)):    # clocks settle
+                            fn()
+                        torch.cuda.synchronize()
+                        zr.trace_begin(50)
+                        for _ in range(50):
+                            fn()
+                        passes.append(statistics.mean(zr.trace_end(50)))
+                    ms = statistics.median(passes)
+                    row[name][mode] = {"kernel_ms_median": round(ms, 4), "kernel_ms_min": round(min(passes), 4),
+                                       "kernel_ms_max": round(max(passes), 4),
+                                       "algorithmic_GBps": round(traffic * n / 1e9 / (ms / 1e3), 1),
+                                       "frac_of_8TBps": round(traffic * n / 1e9 / (ms / 1e3) / 8000, 3),
+                                       "frac_range": [round(traffic * n / 1e9 / (max(passes) / 1e3) / 8000, 3),
+                                                      round(traffic * n / 1e9 / (min(passes) / 1e3) / 8000, 3)]}
+                a0, d0 = slices[0]
+                row[name]["step_ms_incl_finalize"] = round(gpu_time_ms(lambda: call(a0, d0), 10, torch), 4)
             rows.append(row)
         report["cfg2"] = rows
         del big, dst
