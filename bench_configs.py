@@ -365,7 +365,7 @@ def main():
             "ratio": round(n / clen, 3), "compressed_MiB": round(clen / 2**20, 2),
             "step_s_incl_host_sync": round(step, 4), "input_GBps": round(n / 1e9 / step, 2),
             "algorithmic_GBps_U_plus_C": round((n + clen) / 1e9 / step, 2),
-            "lz_chain_kernel_ms": round(k1[0], 2) if k1 else None,
+            "lz_rows_kernel_ms": round(k1[0], 2) if k1 else None,
             "cpu_python_zlib_level6_in_MBps_1thread": round(len(sample) / 1e6 / t_z6, 1),
             "cpu_python_zlib_level6_ratio_on_first_32MiB": round(len(sample) / z6, 3)}
         del src, dst

@@ -88,14 +88,74 @@ static uint32_t row_find(size_t p, uint32_t maxlen, uint32_t *dist) {     // p a
     return best >= 4 ? best : 0;
 }
 
+// ---- rows, batch form: the kernel inserts a whole batch of BATCH positions, then searches; a lane sees (A) the row as it
+// was before the batch (read before the inserts) and (C) the row after all inserts, of which only positions inside the
+// batch and below its own are new information.  Up to two tables, keyed by the first KB bytes (4 and e.g. 7).
+static int batch = 1024; static size_t batch_base = (size_t)-1;
+typedef struct { int rows, entries, kb; uint16_t *pos, *tag, *spos, *stag; uint32_t *cnt; } Tab;
+static Tab tabs[2]; static int ntabs;
+static inline uint64_t rd64(size_t p) { uint64_t v; memcpy(&v, buf + p, 8); return v; }
+static inline void tab_key(const Tab *T, size_t p, uint32_t *row, uint32_t *tag) {
+    uint64_t v = rd64(p); if (T->kb < 8) v &= (1ull << (8 * T->kb)) - 1;
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    uint32_t h = (lo * 2654435761u) ^ (hi * 0x7FEB352Du) ^ ((hi * 0x846CA68Bu) >> 15);
+    uint32_t g = (lo * 0x85EBCA6Bu) ^ (hi * 0xC2B2AE35u);
+    *row = (uint32_t)(((uint64_t)h * (uint64_t)T->rows) >> 32);
+    *tag = (g >> 24) & ((1u << tagbits) - 1);
+}
+static void tab_init(Tab *T, int rows_, int entries_, int kb) {
+    T->rows = rows_; T->entries = entries_; T->kb = kb; size_t m = (size_t)rows_ * entries_;
+    T->pos = calloc(m, 2); T->tag = calloc(m, 2); T->spos = calloc(m, 2); T->stag = calloc(m, 2); T->cnt = calloc(rows_, 4);
+}
+static void rowb_begin(size_t P) {          // snapshot, then insert [P, P + batch)
+    for (int k = 0; k < ntabs; ++k) { Tab *T = &tabs[k]; size_t m = (size_t)T->rows * T->entries;
+        memcpy(T->spos, T->pos, m * 2); memcpy(T->stag, T->tag, m * 2);
+        for (size_t q = P; q < P + batch && q + 8 <= n + 8; ++q) { uint32_t r, t; tab_key(T, q, &r, &t);
+            uint32_t s = T->cnt[r]++ % T->entries; T->pos[(size_t)r * T->entries + s] = (uint16_t)q; T->tag[(size_t)r * T->entries + s] = (uint16_t)(t | 0x8000); } }
+    batch_base = P;
+}
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+static uint32_t rowb_find(size_t p, uint32_t maxlen, uint32_t *dist) {
+    size_t P = p - p % batch;
+    if (P != batch_base) rowb_begin(P);
+    uint32_t best = 3, bd = 0;
+    for (int k = ntabs - 1; k >= 0; --k) {                                  // the long key first
+        Tab *T = &tabs[k]; uint32_t r, t; tab_key(T, p, &r, &t);
+        uint32_t ds[64]; int nd = 0;
+        for (int e = 0; e < T->entries; ++e) {                              // C: after the inserts, inside the batch, below p
+            if (T->tag[(size_t)r * T->entries + e] != (uint16_t)(t | 0x8000)) continue;
+            uint32_t d = (uint16_t)((uint16_t)p - T->pos[(size_t)r * T->entries + e]);
+            if (d >= 1 && d <= p - P && d <= MAXDIST) ds[nd++] = d;
+        }
+        for (int e = 0; e < T->entries; ++e) {                              // A: before the batch
+            if (T->stag[(size_t)r * T->entries + e] != (uint16_t)(t | 0x8000)) continue;
+            uint32_t d = (uint16_t)((uint16_t)p - T->spos[(size_t)r * T->entries + e]);
+            if (d > p - P && d <= MAXDIST && d <= p) ds[nd++] = d;
+        }
+        qsort(ds, nd, 4, cmp_u32);
+        int cand = maxcand;
+        for (int i = 0; i < nd && cand > 0; ++i) {
+            size_t c = p - ds[i];
+            --cand; ++n_cand_reads;
+            if (best < maxlen && buf[c + best] != buf[p + best]) continue;
+            ++n_verify;
+            uint32_t l = match_len(p, c, maxlen);
+            if (l > best) { best = l; bd = ds[i]; if (l >= PROBE || l >= maxlen) goto out; }
+        }
+    }
+out:
+    *dist = bd;
+    return best >= 4 ? best : 0;
+}
 static int mode; static int rep_probe;
 static uint32_t find(size_t p, uint32_t *dist) {
     uint32_t maxlen = n - p < MAXLEN ? (uint32_t)(n - p) : MAXLEN;
     if (maxlen < 4) return 0;
-    uint32_t l = mode == 0 ? chain_find(p, maxlen, dist) : row_find(p, maxlen, dist);
-    if (rep_probe && p >= 1) {                                      // distance-1 probe (runs)
-        uint32_t l1 = match_len(p, p - 1, maxlen);
-        if (l1 >= 4 && l1 > l) { l = l1; *dist = 1; }
+    uint32_t l = mode == 0 ? chain_find(p, maxlen, dist) : mode == 1 ? row_find(p, maxlen, dist) : rowb_find(p, maxlen, dist);
+    for (int d = 1; d <= rep_probe && (size_t)d <= p; ++d) {        // short-distance probes (runs, small periods)
+        if (rd32(p) != rd32(p - d)) continue;
+        uint32_t l1 = match_len(p, p - d, maxlen);
+        if (l1 >= 4 && l1 > l) { l = l1; *dist = d; }
     }
     if (l >= PROBE) l = match_len(p, p - *dist, maxlen);
     return l;
@@ -120,19 +180,69 @@ int main(int argc, char **argv) {
     int a = 3;
     if (!strcmp(argv[2], "chain")) { mode = 0; hbits = atoi(argv[a++]); maxchain = atoi(argv[a++]);
         head = calloc(1u << hbits, 4); prevd = calloc(32768, 2); }
+    else if (!strcmp(argv[2], "rowb")) { mode = 2; rows = atoi(argv[a++]); entries = atoi(argv[a++]); tagbits = atoi(argv[a++]); maxcand = atoi(argv[a++]);
+        tab_init(&tabs[0], rows, entries, 4); ntabs = 1; }
     else { mode = 1; rows = atoi(argv[a++]); entries = atoi(argv[a++]); tagbits = atoi(argv[a++]); maxcand = atoi(argv[a++]);
         rpos = calloc((size_t)rows * entries, 2); rtag = calloc((size_t)rows * entries, 2); rcnt = calloc(rows, 4); }
     rep_probe = argc > a ? atoi(argv[a++]) : 0;
-    int lazy2 = argc > a ? atoi(argv[a++]) : 0;
+    int lazy2 = argc > a ? atoi(argv[a++]) : 0; if (argc > a) batch = atoi(argv[a++]);
+    if (argc > a + 2) { int r2 = atoi(argv[a++]), e2 = atoi(argv[a++]), kb = atoi(argv[a++]); tab_init(&tabs[1], r2, e2, kb); ntabs = 2; }
     const size_t seg = 512 << 10;
     double total_bits = 0; uint32_t lf[286], df[30]; double extra = 0;
     memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
     size_t p = 0, next_seg = seg, ins = 0; unsigned long long nmatch = 0, nlit = 0, mbytes = 0;
     // the kernel searches EVERY position (matches are known everywhere); the serial parse below uses them lazily
     uint32_t curl = 0, curd = 0; int have = 0;
+    if (getenv("PARSE")) {
+        // region DP: every REGION positions are parsed optimally for the current cost estimate given ONE longest match per
+        // position (optionally truncated); the parse of a region is followed from wherever the previous region's last token
+        // ended (exact stitching); costs come from the symbols chosen so far in this segment
+        const int REGION = getenv("REGION") ? atoi(getenv("REGION")) : 64;
+        const int trunc = strstr(getenv("PARSE"), "trunc") != NULL;
+        const int adapt = strstr(getenv("PARSE"), "static") == NULL;
+        static uint32_t L[4096], D[4096]; static double C[4096 + 300]; static uint16_t ch[4096];
+        double lc[286], dc[30];
+        uint32_t hl[286], hd[30];
+        #define RESET_COSTS() do { for (int i = 0; i < 256; ++i) lc[i] = 8; for (int i = 256; i < 286; ++i) lc[i] = 7; for (int i = 0; i < 30; ++i) dc[i] = 5; \
+            memset(hl, 0, sizeof hl); memset(hd, 0, sizeof hd); } while (0)
+        RESET_COSTS();
+        size_t cover = 0, since = 0; double beta = getenv("BETA") ? atof(getenv("BETA")) : 4.0; const size_t refresh = getenv("REFRESH") ? atoi(getenv("REFRESH")) : 4096;
+        for (size_t w0 = 0; w0 < n; w0 += REGION) {
+            if (w0 >= next_seg) { lf[256]++; total_bits += cost_block(lf, df, extra); memset(lf, 0, sizeof lf); memset(df, 0, sizeof df); extra = 0; next_seg += seg; RESET_COSTS(); since = 0; }
+            size_t end = w0 + REGION < n ? w0 + REGION : n; int m = (int)(end - w0);
+            for (int i = 0; i < m; ++i) { uint32_t d = 0; L[i] = find(w0 + i, &d); D[i] = d; ++n_pos;
+                if (w0 + i + L[i] > next_seg) L[i] = (uint32_t)(next_seg - (w0 + i)) >= 4 ? (uint32_t)(next_seg - (w0 + i)) : 0; }
+            for (int x = m; x < m + 300; ++x) C[x] = -beta * (x - m);
+            for (int i = m - 1; i >= 0; --i) {
+                double best = lc[buf[w0 + i]] + C[i + 1]; int bl = 1;
+                if (L[i] >= 4) {
+                    uint32_t eb; int dsym = dist_sym(D[i], &eb); double dcost = dc[dsym] + eb;
+                    for (uint32_t l = trunc ? 4 : L[i]; l <= L[i]; ++l) {
+                        uint32_t el; if (l > 64 && l != L[i]) continue; int ls = len_sym(l, &el); double c = lc[ls] + el + dcost + C[i + l];
+                        if (c < best) { best = c; bl = (int)l; }
+                    }
+                }
+                C[i] = best; ch[i] = (uint16_t)bl;
+            }
+            while (cover < end) {
+                int i = (int)(cover - w0); int l = ch[i];
+                if (l == 1) { lf[buf[cover]]++; hl[buf[cover]]++; ++nlit; }
+                else { uint32_t eb; int ls = len_sym(l, &eb); lf[ls]++; hl[ls]++; extra += eb; int dsym = dist_sym(D[i], &eb); df[dsym]++; hd[dsym]++; extra += eb; ++nmatch; mbytes += l; }
+                cover += l;
+            }
+            since += m;
+            if (adapt && since >= refresh) {            // refresh the cost estimate from the symbols of this segment so far
+                double tl = 1, td = 1; for (int i = 0; i < 286; ++i) tl += hl[i] + 0.5; for (int i = 0; i < 30; ++i) td += hd[i] + 0.5;
+                for (int i = 0; i < 286; ++i) { lc[i] = -log2((hl[i] + 0.5) / tl); if (lc[i] > 15) lc[i] = 15; }
+                for (int i = 0; i < 30; ++i) { dc[i] = -log2((hd[i] + 0.5) / td); if (dc[i] > 15) dc[i] = 15; }
+                since = 0;
+            }
+        }
+        p = n;
+    }
     while (p < n) {
         if (p >= next_seg) { lf[256]++; total_bits += cost_block(lf, df, extra); memset(lf, 0, sizeof lf); memset(df, 0, sizeof df); extra = 0; next_seg += seg; }
-        while (ins <= p + 1 && ins + 4 <= n) { if (mode == 0) chain_insert(ins); else row_insert(ins); ++ins; }
+        while (mode != 2 && ins <= p + 1 && ins + 4 <= n) { if (mode == 0) chain_insert(ins); else row_insert(ins); ++ins; }
         uint32_t d0, l0;
         if (have) { l0 = curl; d0 = curd; have = 0; } else { l0 = find(p, &d0); ++n_pos; }
         uint32_t l1 = 0, d1 = 0;
@@ -142,7 +252,7 @@ int main(int argc, char **argv) {
             ++nmatch; mbytes += l0;
             // positions inside the match are inserted (deflate_medium inserts them all)
             size_t e = p + l0;
-            while (ins < e && ins + 4 <= n) { if (mode == 0) chain_insert(ins); else row_insert(ins); ++ins; }
+            while (mode != 2 && ins < e && ins + 4 <= n) { if (mode == 0) chain_insert(ins); else row_insert(ins); ++ins; }
             p = e;
         } else {
             lf[buf[p]]++; ++nlit; ++p;

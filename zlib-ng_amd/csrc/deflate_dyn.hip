@@ -1,28 +1,32 @@
 // deflate_dyn.hip -- level-6 class deflate of ONE large stream on device (BASELINE.json configs[3]).
 //
-// The caller this replaces is deflate_medium (deflate_medium.c:145-277: hash insert, longest_match chain walk,
-// look-ahead for a better match) followed by zng_tr_flush_block's dynamic-tree block (trees.c:625-741), behind
-// DEFLATE_HOOK (deflate.c:1039).  A single zlib stream is strictly serial on a CPU; here the plaintext is
-// already complete in HBM, so it is cut into SEGMENTS that run in parallel:
+// The caller this replaces is deflate_medium (deflate_medium.c:145-277: hash insert, longest_match, look-ahead for a
+// better match) followed by zng_tr_flush_block's dynamic-tree block (trees.c:625-741), behind DEFLATE_HOOK
+// (deflate.c:1039).  A single zlib stream is strictly serial on a CPU; here the plaintext is already complete in HBM,
+// so it is cut into SEGMENTS that run in parallel:
 //
-//   K1 lz_chain_kernel   one workgroup per segment.  The hash table is primed with the 32 KiB that precede the
-//        segment (what deflateSetDictionary / the sliding window would have left there), then the segment is
-//        parsed with the chain-walking front end of deflate_chain.h (head + prev-delta tables AND the 64 KiB
-//        sliding window in LDS, 144.6 KiB).
+//   K1 lz_rows_kernel    one workgroup per segment.  The search rows are primed with the 32 KiB that precede the
+//        segment (what deflateSetDictionary / the sliding window would have left there), then the segment is parsed with
+//        the front end of deflate_rows.h (associative rows AND the 64 KiB sliding window in LDS; shortest-path parse).
 //        Matches may reach back into the previous segment: the output is ONE continuous deflate stream.
-//   K2 emit_dynamic_kernel one workgroup per segment = one dynamic-Huffman block: symbol histogram (LDS atomics),
-//        Huffman code lengths (rank sort + two-queue merge, depth limit by frequency halving), canonical codes,
-//        the RLE-coded length header (trees.c send_all_trees equivalent), then the body bits assembled in an
-//        LDS tile exactly like the static emitter.  Each segment ends with an empty stored block so that it is
-//        byte aligned (what Z_SYNC_FLUSH emits, deflate.c:1064-1076); the last one appends the final empty
-//        static block.  K3 packs the segments back to back.
+//        Output per segment: a bitmap of token starts (1 bit per position; a token's length is the distance to the next
+//        start), the distance of every match (u16 per 4 positions: matches are >= 4 long, so two never share a slot) --
+//        0.625 bytes of scratch per input byte (round 2: a 32-bit selector per byte) -- and the symbol histogram.
+//   K2 emit_dynamic_kernel one workgroup per segment = one dynamic-Huffman block: Huffman code lengths from K1's
+//        histogram (rank sort + two-queue merge, depth limit by frequency halving), canonical codes, the RLE-coded
+//        length header (trees.c send_all_trees equivalent), then the body bits assembled in an LDS tile.  Each segment
+//        ends with an empty stored block so that it is byte aligned (what Z_SYNC_FLUSH emits, deflate.c:1064-1076);
+//        the last one appends the final empty static block.
+//   K3 segments_scan_kernel: the segments' places in the output (a one-block scan, per stream), the compressed sizes,
+//        the out_cap check -- on the device, so the call has no synchronisation before its last kernel;
+//   K4 gather_segments_kernel packs the segments back to back.
 //
 // Per segment the block type is chosen as zng_tr_flush_block does (trees.c:660-719): stored if that is not larger,
 // else static if not larger than dynamic.  Not bit-identical to the reference's stream (different parse, one block
 // per segment); validity is defined by round trip, as in the reference's own tests.
 #include "context.h"
 #include "deflate_dev.h"
-#include "deflate_chain.h"
+#include "deflate_rows.h"
 
 #include <mutex>
 
@@ -31,10 +35,15 @@ namespace zr {
 struct SegJob {
     const uint8_t *in;        // stream base (position 0)
     uint8_t       *out;       // this segment's output slot (4-byte aligned)
+    uint8_t       *dst;       // the stream's output buffer (what K4 packs into)
+    uint64_t       dst_cap;
+    uint64_t       bm_off;    // this segment's token-start bitmap: u64 words from the scratch base
+    uint64_t       d16_off;   // this segment's match distances: u16 entries from the scratch base
     uint32_t       seg_start, seg_end;
     uint32_t       out_cap;
-    uint32_t       is_last;
-    uint64_t       sel_off;   // selector index of stream position 0
+    uint32_t       is_last;     // the block that carries BFINAL
+    uint32_t       first_seg;   // index of the first segment of this segment's stream
+    uint32_t       stream;      // row of the per-stream result table; 0x80000000 set on the stream's last segment
 };
 
 constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block: the largest, and ...
@@ -48,28 +57,47 @@ static uint32_t segment_bytes(size_t in_len, int cus) {
     return seg;
 }
 constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
+constexpr int      kHistWords = 320;           // 288 literal/length + 32 distance counts per segment
+
+// scratch a segment of `bytes` plaintext bytes needs: bitmap words / distance entries (its first batch may start up to
+// one batch in front of the segment)
+static inline size_t seg_bm_words(uint32_t bytes) { return ((size_t)bytes + 2u * kRowBatch) / 64 + 2; }
+static inline size_t seg_d16_entries(uint32_t bytes) { return (((size_t)bytes + 2u * kRowBatch) / 4 + 8) & ~(size_t)3; }
 
 // grid.x = segment.  The plaintext streams through the LDS ring one batch ahead of the parse: 256 lanes fetch the
 // next 1 KiB chunk into a register at the top of a batch and store it into the ring at the top of the next one, so
-// the HBM latency of the fetch is hidden behind a whole batch of chain walking.
-__global__ __launch_bounds__(kChainBatch)
-void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel_base, uint32_t max_chain,
-                     uint32_t good_match) {
-    __shared__ ChainShared sh;
+// the HBM latency of the fetch is hidden behind a whole batch of searching.
+__global__ __launch_bounds__(kRowBatch)
+void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restrict__ bm_base, uint16_t *__restrict__ d16_base,
+                    uint32_t *__restrict__ hist_out, uint32_t max_cand) {
+    __shared__ RowShared sh;
 
     const SegJob job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
     const uint32_t n = job.seg_end;                 // matches never run past the segment
-    uint32_t *sel = sel_base + job.sel_off;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
 
-    for (int i = t; i < (1 << kChainHashBits); i += kChainBatch) sh.head[i] = 0;
-    for (int i = t; i < 32768 / 2; i += kChainBatch) reinterpret_cast<uint32_t *>(sh.prev)[i] = 0;
-    if (t == 0) sh.cover = job.seg_start;
+    for (int i = t; i < kRows * kRowEnt / 2; i += kRowBatch) reinterpret_cast<uint32_t *>(sh.pos)[i] = 0;
+    for (int i = t; i < kRows * kRowEnt / 4; i += kRowBatch) reinterpret_cast<uint32_t *>(sh.tag)[i] = 0;
+    for (int i = t; i < kRows / 4; i += kRowBatch) sh.cnt[i] = 0;
+    if (t < 288) {
+        sh.hist_l[t] = 0;
+        // before the segment has tokens of its own: 8 bits per literal, 7 per length symbol, 5 per distance symbol
+        sh.cost_l[t] = (uint16_t)((t < 256 ? 8u : 7u) * kCostBit);
+    } else if (t < 320) {
+        sh.hist_d[t - 288] = 0;
+        sh.cost_d[t - 288] = (uint16_t)(5u * kCostBit);
+    }
+    if (t == 0) {
+        sh.cover = job.seg_start;
+        sh.tot_l = sh.tot_d = 0;
+    }
 
     uint32_t P0 = job.seg_start > kPrime ? job.seg_start - kPrime : 0u;
-    P0 -= P0 % kChainBatch;
-    const uint32_t first = job.seg_start - job.seg_start % kChainBatch;   // batch holding the segment's first byte
+    P0 -= P0 % kRowBatch;
+    const uint32_t first = job.seg_start - job.seg_start % kRowBatch;   // batch holding the segment's first byte
+    unsigned long long *bm = bm_base + job.bm_off;
+    uint16_t *d16 = d16_base + job.d16_off;
 
     // chunk [F, F + 1024) of the plaintext, one dword per lane of the first four waves; bytes at or beyond n read 0
     auto fetch = [&](uint32_t F) -> uint32_t {
@@ -92,21 +120,44 @@ void lz_chain_kernel(const SegJob *__restrict__ jobs, uint32_t *__restrict__ sel
     uint32_t chunk = fetch(P0 + 2048u);
     __syncthreads();
 
-    for (uint32_t P = P0; P < n; P += kChainBatch) {
+    int since_refresh = 0;
+    for (uint32_t P = P0; P < n; P += kRowBatch) {
         if (P != P0) {
             put(P + kRingAhead, chunk);             // [P + 1024, P + 2048): visible after the insert barriers below
             chunk = fetch(P + kRingAhead + 1024u);
         }
-        const bool prime = P < first;
-        const LzPick r = chain_batch(n, P, &sh, t, max_chain, prime, good_match);
         const uint32_t p = P + (uint32_t)t;
-        if (!prime && p >= job.seg_start && p < n) {
-            uint32_t s = 0;
-            if (r.kind == 2u) s = 0x80000000u | ((r.len - 3u) << 16) | (r.dist - 1u);
-            else if (r.kind == 1u) s = 0x40000000u;
-            __builtin_nontemporal_store(s, sel + p);        // read once, by the emitter, long after
+        if (P < first) {                            // priming: enter the positions, nothing else
+            const bool can = p + kLzMinMatch <= n;
+            uint32_t row, tag;
+            row_key(ring_u32(sh.ring, p & (kRingBytes - 1u)), row, tag);
+            rows_insert(&sh, can, row, tag, p, __builtin_amdgcn_readfirstlane(t >> 6));
+            continue;
+        }
+        const bool refresh = since_refresh >= kRefreshBatches;
+        since_refresh = refresh ? 1 : since_refresh + 1;
+        unsigned long long starts;
+        const RowsToken r = rows_batch(n, P, P0, &sh, t, max_cand, refresh, &starts);
+        const unsigned long long matches = __ballot(r.kind == 2u);
+        if (lane == 0) {
+            bm[(P - first) / 64u + (uint32_t)(t >> 6)] = starts;
+            const uint32_t nt = (uint32_t)__popcll(starts), nm = (uint32_t)__popcll(matches);
+            if (nt) atomicAdd(&sh.tot_l, nt);
+            if (nm) atomicAdd(&sh.tot_d, nm);
+        }
+        if (r.kind == 2u) {
+            uint32_t sy, eb;
+            rows_len_symbol(r.len, sy, eb);
+            atomicAdd(&sh.hist_l[sy], 1u);
+            rows_dist_symbol(r.dist, sy, eb);
+            atomicAdd(&sh.hist_d[sy], 1u);
+            d16[(p - first) >> 2] = (uint16_t)(r.dist - 1u);
+        } else if (r.kind == 1u) {
+            atomicAdd(&sh.hist_l[sh.ring[p & (kRingBytes - 1u)]], 1u);
         }
     }
+    __syncthreads();
+    if (t < kHistWords) hist_out[(size_t)blockIdx.x * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];
 }
 
 // ---- dynamic Huffman ---------------------------------------------------------------------------------------
@@ -275,8 +326,30 @@ __device__ __forceinline__ void lds_put(uint32_t *obuf, uint32_t &cur, uint32_t 
     cur += nb;
 }
 
+// first token start behind bit `rel` of a segment's bitmap, or hi_rel (the segment's end) if there is none below it
+__device__ __forceinline__ uint32_t next_start_rel(const unsigned long long *bm, uint32_t rel, uint32_t hi_rel) {
+    uint32_t q = rel + 1u;
+    if (q >= hi_rel) return hi_rel;
+    unsigned long long w = bm[q >> 6] >> (q & 63u);
+    if (w) {
+        q += (uint32_t)__builtin_ctzll(w);
+        return q < hi_rel ? q : hi_rel;
+    }
+    q = (q | 63u) + 1u;
+    while (q < hi_rel) {
+        w = bm[q >> 6];
+        if (w) {
+            q += (uint32_t)__builtin_ctzll(w);
+            return q < hi_rel ? q : hi_rel;
+        }
+        q += 64u;
+    }
+    return hi_rel;
+}
+
 __global__ __launch_bounds__(256)
-void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ sel_base,
+void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long long *__restrict__ bm_base,
+                         const uint16_t *__restrict__ d16_base, const uint32_t *__restrict__ hist_in,
                          uint32_t *__restrict__ seg_len) {
     __shared__ DynTables T;
     __shared__ uint32_t obuf[kDynWords];
@@ -286,27 +359,16 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
     const SegJob job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
     const uint32_t lo = job.seg_start, hi = job.seg_end;
-    const uint32_t *sel = sel_base + job.sel_off;
+    const uint32_t first = lo - lo % kRowBatch;              // position of bit 0 of the segment's bitmap
+    const unsigned long long *bm = bm_base + job.bm_off;
+    const uint16_t *d16 = d16_base + job.d16_off;
+    const uint32_t hi_rel = hi - first;
     uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    // 1. histogram
-    for (int i = t; i < 288; i += 256) T.lfreq[i] = 0;
-    if (t < 32) T.dfreq[t] = 0;
-    __syncthreads();
-    for (uint32_t p = lo + (uint32_t)t; p < hi; p += 256) {
-        const uint32_t s = sel[p];
-        if (s & 0x80000000u) {
-            uint32_t sym, eb, ev;
-            len_symbol(((s >> 16) & 0xffu) + 3u, sym, eb, ev);
-            atomicAdd(&T.lfreq[sym], 1u);
-            dist_symbol((s & 0xffffu) + 1u, sym, eb, ev);
-            atomicAdd(&T.dfreq[sym], 1u);
-        } else if (s & 0x40000000u) {
-            atomicAdd(&T.lfreq[in[p]], 1u);
-        }
-    }
-    if (t == 0) atomicAdd(&T.lfreq[256], 1u);           // end-of-block
+    // 1. histogram: counted by K1 while it chose the tokens
+    for (int i = t; i < 288; i += 256) T.lfreq[i] = hist_in[(size_t)blockIdx.x * kHistWords + i] + (i == 256 ? 1u : 0u);   // + end-of-block
+    if (t < 32) T.dfreq[t] = hist_in[(size_t)blockIdx.x * kHistWords + 288 + t];
     __syncthreads();
     for (int i = t; i < 288; i += 256) T.lfreq0[i] = T.lfreq[i];
     if (t < 32) T.dfreq0[t] = T.dfreq[t];
@@ -485,30 +547,37 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
         } else {
             for (uint32_t q = p0; q < hi; ++q) rw[(q - p0) >> 2] |= (uint32_t)in[q] << (8u * ((q - p0) & 3u));
         }
-        uint32_t sv[kDynPer];                            // 16 selectors as four dwordx4 loads (segments start 16-aligned)
-#pragma unroll
-        for (int q = 0; q < kDynPer / 4; ++q) {
-            uint4 v4 = make_uint4(0, 0, 0, 0);
-            if (p0 < hi) v4 = reinterpret_cast<const uint4 *>(sel + p0)[q];
-            sv[4 * q] = v4.x; sv[4 * q + 1] = v4.y; sv[4 * q + 2] = v4.z; sv[4 * q + 3] = v4.w;
+        // the token starts among this lane's 16 positions, and 48 bits of look-ahead for their lengths
+        unsigned long long win = 0;
+        const uint32_t rel0 = p0 - first;
+        if (p0 < hi) {
+            const uint32_t sft = rel0 & 63u;
+            win = bm[rel0 >> 6] >> sft;
+            if (sft) win |= bm[(rel0 >> 6) + 1] << (64u - sft);
         }
 #pragma unroll
         for (int j = 0; j < kDynPer; ++j) {
             const uint32_t p = p0 + (uint32_t)j;
-            const uint32_t s = p < hi ? sv[j] : 0u;
             c1[j] = n1[j] = c2[j] = n2[j] = 0;
-            if (s & 0x80000000u) {
-                uint32_t sym, eb, ev;
-                len_symbol(((s >> 16) & 0xffu) + 3u, sym, eb, ev);
-                c1[j] = (uint32_t)T.lcode[sym] | (ev << T.llen[sym]);
-                n1[j] = T.llen[sym] + eb;
-                dist_symbol((s & 0xffffu) + 1u, sym, eb, ev);
-                c2[j] = (uint32_t)T.dcode[sym] | (ev << T.dlen[sym]);
-                n2[j] = T.dlen[sym] + eb;
-            } else if (s & 0x40000000u) {
-                const uint32_t b = (rw[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                c1[j] = T.lcode[b];
-                n1[j] = T.llen[b];
+            if (p < hi && ((win >> j) & 1ull)) {
+                const unsigned long long ahead = win >> (j + 1);
+                uint32_t nx = ahead ? rel0 + (uint32_t)j + 1u + (uint32_t)__builtin_ctzll(ahead)
+                                    : next_start_rel(bm, rel0 + 63u, hi_rel);      // a match that outruns the window
+                if (nx > hi_rel) nx = hi_rel;
+                const uint32_t len = nx - (rel0 + (uint32_t)j);
+                if (len > 1u) {
+                    uint32_t sym, eb, ev;
+                    len_symbol(len, sym, eb, ev);
+                    c1[j] = (uint32_t)T.lcode[sym] | (ev << T.llen[sym]);
+                    n1[j] = T.llen[sym] + eb;
+                    dist_symbol((uint32_t)d16[(rel0 + (uint32_t)j) >> 2] + 1u, sym, eb, ev);
+                    c2[j] = (uint32_t)T.dcode[sym] | (ev << T.dlen[sym]);
+                    n2[j] = T.dlen[sym] + eb;
+                } else {
+                    const uint32_t b = (rw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    c1[j] = T.lcode[b];
+                    n1[j] = T.llen[b];
+                }
             }
             mine += n1[j] + n2[j];
         }
@@ -574,14 +643,64 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const uint32_t *__rest
     }
 }
 
-// K3: pack the segments back to back (byte granular)
+// K3: every segment's place in its stream's output -- an exclusive scan of the segment lengths, restarted per stream --
+// plus the per-stream totals and the out_cap check.  One workgroup; `excl` = nseg + 1 u64 of scratch.
+//   results[2 * s] = compressed size of stream s, results[2 * s + 1] = 1 if it does not fit its buffer
+__global__ __launch_bounds__(1024)
+void segments_scan_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len, uint32_t nseg,
+                          unsigned long long *__restrict__ excl, unsigned long long *__restrict__ dst_off,
+                          unsigned long long *__restrict__ results) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nseg; base += 1024u) {
+        const uint32_t k = base + (uint32_t)t;
+        const unsigned long long v = k < nseg ? seg_len[k] : 0ull;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        if (k < nseg) excl[k] = before + incl - v;
+        __syncthreads();
+        if (t == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) excl[nseg] = carry;
+    __syncthreads();                                     // one workgroup: its own global stores are visible to it
+    for (uint32_t k = (uint32_t)t; k < nseg; k += 1024u) {
+        const SegJob &j = jobs[k];
+        const unsigned long long off = excl[k] - excl[j.first_seg];
+        dst_off[k] = off;
+        if (j.stream & 0x80000000u) {
+            const uint32_t srow = j.stream & 0x7fffffffu;
+            const unsigned long long total = off + seg_len[k];
+            results[2 * srow] = total;
+            results[2 * srow + 1] = total > j.dst_cap ? 1ull : 0ull;
+        }
+    }
+}
+
+// K4: pack the segments back to back (byte granular); a stream that does not fit its buffer is cut at the buffer's end
+// (K3 has flagged it)
 __global__ __launch_bounds__(256)
 void gather_segments_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len,
-                            const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst) {
+                            const unsigned long long *__restrict__ dst_off) {
     const SegJob job = jobs[blockIdx.y];
-    const uint32_t n = seg_len[blockIdx.y];
-    uint8_t *d = dst + dst_off[blockIdx.y];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = job.out[i];
+    const unsigned long long off = dst_off[blockIdx.y];
+    unsigned long long n = seg_len[blockIdx.y];
+    if (off >= job.dst_cap) return;
+    if (off + n > job.dst_cap) n = job.dst_cap - off;
+    uint8_t *d = job.dst + off;
+    for (unsigned long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        d[i] = job.out[i];
 }
 
 // Level 0: deflate_stored (deflate_stored.c:27-186) for a complete, device-resident plaintext and an output buffer
@@ -622,6 +741,83 @@ void stored_kernel(const uint8_t *__restrict__ in, size_t n, uint8_t *__restrict
 static inline size_t seg_slot_bytes(uint32_t n) {
     // <= 9 bits per literal for an almost flat alphabet, + header (< 400 bytes) + trailer; 4-byte aligned
     return (((size_t)n * 9 + 7) / 8 + 1024 + 3) & ~(size_t)3;
+}
+
+// candidates looked at per position, per level: the row form of max_chain_length (deflate.c:142-168: 4, 6, 24, 32, 128
+// links at levels 2..6); level 1 = deflate_quick's single probe (deflate_quick.c:89-97)
+static const uint32_t kLevelCand[10] = {0, 1, 2, 3, 6, 8, 16, 16, 16, 16};
+
+// The launches of one round: `njobs` streams, all their segments in one job list.  Asynchronous on `st`; *results =
+// pinned host words {compressed size, does-not-fit flag} per stream, valid once the stream has been synchronised.
+// cap_override: out_cap of job 0 when the caller's job struct cannot hold it (a single stream of >= 4 GiB of room).
+static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, size_t njobs, const size_t *cap_override,
+                                uint32_t seg_bytes, Workspace *ws, hipStream_t st, unsigned long long **results) {
+    size_t nseg = 0;
+    for (size_t s = 0; s < njobs; ++s) nseg += sjobs[s].in_len ? ((size_t)sjobs[s].in_len + seg_bytes - 1) / seg_bytes : 1;
+    SegJob *d_jobs = nullptr, *jobs = nullptr;
+    uint32_t *d_seg_len = nullptr, *d_hist = nullptr;
+    unsigned long long *d_scan = nullptr, *d_bm = nullptr, *d_res = nullptr, *h_res = nullptr;
+    uint16_t *d_d16 = nullptr;
+    uint8_t *d_slots = nullptr;
+    if (int rc = host_tables_acquire(ws)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSegLenHost, njobs * 2 * sizeof(unsigned long long), true, (void **)&h_res)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
+    if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * (sizeof(uint32_t) + kHistWords * sizeof(uint32_t)), false, (void **)&d_seg_len))
+        return rc;
+    d_hist = d_seg_len + ((nseg + 3) & ~(size_t)3);
+    if (int rc = scratch_reserve(ws, kScrDynDstOff, (2 * nseg + 2 + 2 * njobs) * sizeof(unsigned long long), false, (void **)&d_scan))
+        return rc;
+    unsigned long long *d_excl = d_scan, *d_dst_off = d_scan + nseg + 1;
+    d_res = d_dst_off + nseg + 1;
+    size_t slot_total = 0, bm_total = 0, d16_total = 0, k = 0;
+    for (size_t s = 0; s < njobs; ++s) {
+        const zng_rocm_stream_job &j = sjobs[s];
+        const uint32_t dict = j.dict_len;
+        const bool final_block = (j.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
+        const size_t n = j.in_len ? ((size_t)j.in_len + seg_bytes - 1) / seg_bytes : 1;
+        const size_t k0 = k;
+        for (size_t i = 0; i < n; ++i, ++k) {
+            // positions count from the first dictionary byte: the segments' own 32 KiB priming reaches into it
+            const uint32_t a = dict + (uint32_t)(i * seg_bytes);
+            const uint32_t b = dict + (uint32_t)((i + 1) * (size_t)seg_bytes < j.in_len ? (i + 1) * (size_t)seg_bytes : j.in_len);
+            jobs[k].in = (const uint8_t *)j.in - dict;
+            jobs[k].dst = (uint8_t *)j.out;
+            jobs[k].dst_cap = cap_override && s == 0 ? *cap_override : j.out_cap;
+            jobs[k].seg_start = a;
+            jobs[k].seg_end = b;
+            jobs[k].out_cap = (uint32_t)seg_slot_bytes(b - a);
+            jobs[k].is_last = (i + 1 == n && final_block) ? 1 : 0;
+            jobs[k].first_seg = (uint32_t)k0;
+            jobs[k].stream = (uint32_t)s | (i + 1 == n ? 0x80000000u : 0u);
+            jobs[k].out = (uint8_t *)slot_total;          // offset for now
+            jobs[k].bm_off = bm_total;
+            jobs[k].d16_off = d16_total;
+            slot_total += jobs[k].out_cap;
+            bm_total += seg_bm_words(b - a);
+            d16_total += seg_d16_entries(b - a);
+        }
+    }
+    if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
+    // token scratch of the matcher: 1 bit + half a u16 per position (K1 -> K2)
+    if (int rc = scratch_reserve(ws, kScrDynSel, bm_total * sizeof(unsigned long long) + d16_total * sizeof(uint16_t), false, (void **)&d_bm))
+        return rc;
+    d_d16 = reinterpret_cast<uint16_t *>(d_bm + bm_total);
+    for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
+    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
+
+    ZR_LAUNCH_TRACED(lz_rows_kernel, dim3((unsigned)nseg), dim3(kRowBatch), st, d_jobs, d_bm, d_d16, d_hist, kLevelCand[level] | (getenv("ZR_EXP") ? (uint32_t)atoi(getenv("ZR_EXP")) << 8 : 0u));
+    ZR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_bm, d_d16, d_hist, d_seg_len);
+    ZR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(segments_scan_kernel, dim3(1), dim3(1024), 0, st, d_jobs, d_seg_len, (uint32_t)nseg, d_excl, d_dst_off, d_res);
+    ZR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(njobs > 64 ? 4 : 16, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off);
+    ZR_HIP(hipGetLastError());
+    ZR_HIP(hipMemcpyAsync(h_res, d_res, njobs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (int rc = host_tables_release(ws, st)) return rc;
+    *results = h_res;
+    return ZNG_ROCM_OK;
 }
 
 }  // namespace zr
@@ -694,76 +890,29 @@ int zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, ui
         *out_len = total0;
         return ZNG_ROCM_OK;
     }
-    // level 1 here = deflate_quick's matcher (one probe of the chain head, deflate_quick.c:89-97) run segment-parallel
-    // on ONE large stream; the many-stream form of level 1 is zng_rocm_deflate_quick_dev
-    static const uint32_t chains[10] = {0, 1, 4, 6, 24, 32, 128, 256, 1024, 4096};
-    uint32_t max_chain = chains[level];
-    if (max_chain > 256) max_chain = 256;
-    static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};     // good_match per level, deflate.c:142-168
-    const uint32_t good_match = goods[level];
-
     const size_t seg_bytes = segment_bytes(in_len, ctx()->cus);
-    const size_t nseg = in_len ? (in_len + seg_bytes - 1) / seg_bytes : 1;
-    SegJob *d_jobs = nullptr, *jobs = nullptr;
-    uint32_t *d_sel = nullptr, *d_seg_len = nullptr, *lens = nullptr;
-    uint64_t *d_dst_off = nullptr, *offs = nullptr;
-    uint8_t *d_slots = nullptr;
-    if (int rc = host_tables_acquire(ws)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynSegLenHost, nseg * sizeof(uint32_t), true, (void **)&lens)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynDstOffHost, nseg * sizeof(uint64_t), true, (void **)&offs)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * sizeof(uint32_t), false, (void **)&d_seg_len)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynDstOff, nseg * sizeof(uint64_t), false, (void **)&d_dst_off)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynSel, (in_len + dict_len + 1024 + 4) * sizeof(uint32_t), false, (void **)&d_sel)) return rc;
-    size_t slot_total = 0;
-    for (size_t i = 0; i < nseg; ++i) {
-        // positions count from the first dictionary byte: the segments' own 32 KiB priming reaches into it
-        const uint32_t a = dict_len + (uint32_t)(i * seg_bytes);
-        const uint32_t b = dict_len + (uint32_t)((i + 1) * seg_bytes < in_len ? (i + 1) * seg_bytes : in_len);
-        jobs[i].in = d_in - dict_len;
-        jobs[i].seg_start = a;
-        jobs[i].seg_end = b;
-        jobs[i].out_cap = (uint32_t)seg_slot_bytes(b - a);
-        jobs[i].is_last = (i + 1 == nseg && final_block) ? 1 : 0;
-        jobs[i].sel_off = (4u - dict_len % 4u) % 4u;      // selector of a segment's first byte stays 16-byte aligned
-        jobs[i].out = (uint8_t *)slot_total;          // offset for now
-        slot_total += jobs[i].out_cap;
-    }
-    if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
-    for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
-    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
-
-    ZR_LAUNCH_TRACED(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), st, d_jobs, d_sel, max_chain, good_match);
-    ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_sel, d_seg_len);
-    ZR_HIP(hipGetLastError());
-
-    // segment lengths -> offsets (host; the one mid-call synchronisation of this entry point)
-    ZR_HIP(hipMemcpyAsync(lens, d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    zng_rocm_stream_job one;
+    one.in = d_in;
+    one.out = d_out;
+    one.in_len = (uint32_t)in_len;
+    one.out_cap = 0;
+    one.dict_len = dict_len;
+    one.flags = flags;
+    unsigned long long *res = nullptr;
+    if (int rc = deflate_rows_enqueue(level, &one, 1, &out_cap, (uint32_t)seg_bytes, ws, st, &res)) return rc;
     ZR_HIP(hipStreamSynchronize(st));
-    uint64_t total = 0;
-    for (size_t i = 0; i < nseg; ++i) {
-        offs[i] = total;
-        total += lens[i];
-    }
-    if (total > out_cap) {
-        set_error("compressed size %llu exceeds out_cap", (unsigned long long)total);
+    if (res[1]) {
+        set_error("compressed size %llu exceeds out_cap", res[0]);
         return -5;
     }
-    ZR_HIP(hipMemcpyAsync(d_dst_off, offs, nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_segments_kernel, dim3(16, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off,
-                       d_out);
-    ZR_HIP(hipGetLastError());
-    ZR_HIP(hipStreamSynchronize(st));
-    *out_len = (size_t)total;
+    *out_len = (size_t)res[0];
     return ZNG_ROCM_OK;
 }
 
 // Many independent streams at one of the chain levels (the reference's many-stream model, test/pigz/CMakeLists.txt:123-200,
 // at pigz's default level): every stream is cut into segments as in zng_rocm_deflate_block_dev and the segments of ALL
-// streams go through ONE set of launches per round (a round holds up to ~1 GiB of plaintext: the matcher's selectors
-// are 4 bytes per input byte).  Synchronous, like zng_rocm_deflate_block_dev; out_lens is a host array.
+// streams go through ONE set of launches per round (a round holds up to ~4 GiB of plaintext).  Synchronous, like
+// zng_rocm_deflate_block_dev; out_lens is a host array.
 int zng_rocm_deflate_streams_dev(int level, const zng_rocm_stream_job *sjobs, size_t njobs, size_t *out_lens, void *stream) {
     if (!ctx()) {
         set_error("zng_rocm_init() has not succeeded");
@@ -795,86 +944,26 @@ int zng_rocm_deflate_streams_dev(int level, const zng_rocm_stream_job *sjobs, si
     Workspace *ws = workspace_for(st);
     if (!ws) return ZNG_ROCM_ENOMEM;
     std::lock_guard<std::mutex> use(ws->mu);
-    static const uint32_t chains[10] = {0, 1, 4, 6, 24, 32, 128, 256, 1024, 4096};     // deflate.c:142-168
-    static const uint32_t goods[10] = {0, 0, 4, 4, 4, 8, 8, 8, 32, 32};
-    const uint32_t max_chain = chains[level] > 256 ? 256 : chains[level], good_match = goods[level];
     const uint32_t seg_bytes = segment_bytes(total_in, ctx()->cus);
-    constexpr size_t kRoundBytes = 1ull << 30;
+    constexpr size_t kRoundBytes = 4ull << 30;
 
     size_t first = 0;
     while (first < njobs) {
-        // the streams of this round, and how many segments they make
-        size_t last = first, bytes = 0, nseg = 0;
+        size_t last = first, bytes = 0;
         while (last < njobs && (last == first || bytes + sjobs[last].in_len + sjobs[last].dict_len <= kRoundBytes)) {
-            bytes += sjobs[last].in_len + sjobs[last].dict_len + 8;
-            nseg += sjobs[last].in_len ? (sjobs[last].in_len + seg_bytes - 1) / seg_bytes : 1;
+            bytes += sjobs[last].in_len + sjobs[last].dict_len;
             ++last;
         }
-        SegJob *d_jobs = nullptr, *jobs = nullptr;
-        uint32_t *d_sel = nullptr, *d_seg_len = nullptr, *lens = nullptr;
-        uint64_t *d_dst_off = nullptr, *offs = nullptr;
-        uint8_t *d_slots = nullptr;
-        if (int rc = host_tables_acquire(ws)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynSegLenHost, nseg * sizeof(uint32_t), true, (void **)&lens)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynDstOffHost, nseg * sizeof(uint64_t), true, (void **)&offs)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * sizeof(uint32_t), false, (void **)&d_seg_len)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynDstOff, nseg * sizeof(uint64_t), false, (void **)&d_dst_off)) return rc;
-        if (int rc = scratch_reserve(ws, kScrDynSel, (bytes + 1024 * (last - first) + 1024) * sizeof(uint32_t), false, (void **)&d_sel))
-            return rc;
-        size_t slot_total = 0, k = 0;
-        uint64_t sel_at = 0;
-        for (size_t s = first; s < last; ++s) {
-            const zng_rocm_stream_job &j = sjobs[s];
-            const uint32_t dict = j.dict_len;
-            const bool final_block = (j.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
-            const size_t n = j.in_len ? (j.in_len + seg_bytes - 1) / seg_bytes : 1;
-            sel_at = (sel_at + 3u) & ~(uint64_t)3u;
-            for (size_t i = 0; i < n; ++i, ++k) {
-                const uint32_t a = dict + (uint32_t)(i * seg_bytes);
-                const uint32_t b = dict + (uint32_t)((i + 1) * (size_t)seg_bytes < j.in_len ? (i + 1) * (size_t)seg_bytes : j.in_len);
-                jobs[k].in = j.in - dict;
-                jobs[k].seg_start = a;
-                jobs[k].seg_end = b;
-                jobs[k].out_cap = (uint32_t)seg_slot_bytes(b - a);
-                jobs[k].is_last = (i + 1 == n && final_block) ? 1 : 0;
-                jobs[k].sel_off = sel_at + (4u - dict % 4u) % 4u;         // selector of a segment's first byte stays 16-byte aligned
-                jobs[k].out = (uint8_t *)slot_total;
-                slot_total += jobs[k].out_cap;
-            }
-            sel_at += (uint64_t)j.in_len + dict + 1024 + 4;
-        }
-        if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
-        for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
-        ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
-        ZR_LAUNCH_TRACED(lz_chain_kernel, dim3((unsigned)nseg), dim3(kChainBatch), st, d_jobs, d_sel, max_chain, good_match);
-        ZR_HIP(hipGetLastError());
-        hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_sel, d_seg_len);
-        ZR_HIP(hipGetLastError());
-        ZR_HIP(hipMemcpyAsync(lens, d_seg_len, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        unsigned long long *res = nullptr;
+        if (int rc = deflate_rows_enqueue(level, sjobs + first, last - first, nullptr, seg_bytes, ws, st, &res)) return rc;
         ZR_HIP(hipStreamSynchronize(st));
-        // every segment's place: absolute addresses inside its stream's output buffer
-        k = 0;
         for (size_t s = first; s < last; ++s) {
-            const zng_rocm_stream_job &j = sjobs[s];
-            const size_t n = j.in_len ? (j.in_len + seg_bytes - 1) / seg_bytes : 1;
-            uint64_t total = 0;
-            for (size_t i = 0; i < n; ++i, ++k) {
-                offs[k] = (uint64_t)(uintptr_t)j.out + total;
-                total += lens[k];
-            }
-            if (total > j.out_cap) {
-                set_error("job %zu: compressed size %llu exceeds out_cap", s, (unsigned long long)total);
+            if (res[2 * (s - first) + 1]) {
+                set_error("job %zu: compressed size %llu exceeds out_cap", s, res[2 * (s - first)]);
                 return -5;
             }
-            out_lens[s] = (size_t)total;
+            out_lens[s] = (size_t)res[2 * (s - first)];
         }
-        ZR_HIP(hipMemcpyAsync(d_dst_off, offs, nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(gather_segments_kernel, dim3(4, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off,
-                           (uint8_t *)nullptr);
-        ZR_HIP(hipGetLastError());
-        ZR_HIP(hipStreamSynchronize(st));
         first = last;
     }
     return ZNG_ROCM_OK;

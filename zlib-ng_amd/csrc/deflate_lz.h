@@ -32,7 +32,7 @@ constexpr uint32_t kLzProbe = 32;                             // bytes compared 
 constexpr uint32_t kLzMinMatch = 4;                           // WANT_MIN_MATCH (deflate.h)
 constexpr uint32_t kLzNone = 0xffffffffu;
 
-constexpr uint32_t kLzChainProbe = 64;                        // level-6 class (deflate_chain.h): per-lane compare cap
+
 
 // HBITS: log2 of the head table.  The table is the LDS budget of a stream, and the number of streams a CU can
 // keep in flight is what hides the latency of this (serial-per-stream) code: measured on MI355X, 4096 x 1 MiB,
