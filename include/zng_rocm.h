@@ -430,6 +430,36 @@ int    zng_rocm_compress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *d_
 int    zng_rocm_uncompress2_dev(uint8_t *d_dst, size_t *dst_len, const uint8_t *src, size_t *src_len, int format,
                                 void *stream);
 
+/* ---- the coarse boundary: what DEFLATE_HOOK / INFLATE_TYPEDO_HOOK call ---------------------------------------
+ * A `zng_rocm_hook` is the content of an arch/rocm backend's arch_deflate_state / arch_inflate_state
+ * (deflate.h:319-321, inflate.h:160-162; precedent arch/s390/dfltcc_common.h): the stream's 32 KiB of history in
+ * device memory, a bounded staging buffer, a HIP stream of its own.  Host pointers in and out -- zng_stream's next_in /
+ * next_out are the caller's memory (SURVEY.md 8b "Ownership").  The reference-side adapter that keeps next_in /
+ * avail_in / next_out / avail_out / total_* / adler and answers need_more / block_done / finish_started /
+ * finish_done (deflate.h:336-341, deflate.c:1039-1083) is integration/arch/rocm/rocm_deflate.c, rocm_inflate.c.
+ * Every function returns ZNG_ROCM_ENODEV after a zng_rocm_shutdown() (the adapter then continues in software). */
+typedef struct zng_rocm_hook zng_rocm_hook;
+int    zng_rocm_hook_create(zng_rocm_hook **h, size_t block_bytes);       /* ENODEV without a device */
+void   zng_rocm_hook_destroy(zng_rocm_hook *h);
+int    zng_rocm_hook_reset(zng_rocm_hook *h);                             /* forget the history: deflateResetKeep (deflate.c:567), Z_FULL_FLUSH (deflate.c:1073-1080), inflateResetKeep */
+/* deflateSetDictionary / inflateSetDictionary (deflate.c:456-531, inflate.c:1214-1261): the last 32 KiB become the history */
+int    zng_rocm_hook_set_history(zng_rocm_hook *h, const uint8_t *dict, uint32_t len);
+/* deflateGetDictionary / inflateGetDictionary (deflate.c:521-545, inflate.c:1195-1212): dict may be NULL (length only) */
+int    zng_rocm_hook_get_history(zng_rocm_hook *h, uint8_t *dict, uint32_t *len);
+size_t zng_rocm_hook_deflate_bound(size_t in_len);
+/* One block of the stream: `in` (host) is compressed at `level` (0..9, as zng_rocm_deflate_block_dev) against the
+ * history, the block lands at `out` (host, out_cap >= zng_rocm_hook_deflate_bound(in_len)) and always ends on a byte
+ * boundary; flags = ZNG_ROCM_BLOCK_*; the input becomes history.  check: 0 none, 1 Adler-32, 2 CRC-32 of `in`,
+ * continuing *check_value (what DEFLATE_NEED_CHECKSUM = 0 leaves to the backend, deflate.c:1197-1212). */
+int    zng_rocm_hook_deflate_block(zng_rocm_hook *h, int level, const uint8_t *in, size_t in_len, uint32_t flags, int check,
+                                   uint32_t *check_value, uint8_t *out, size_t out_cap, size_t *out_len);
+/* A complete raw deflate stream (or the rest of one) at `in`, continuing the history: returns 1 (Z_STREAM_END) with the
+ * plaintext at *out (host memory owned by the hook, valid until its next call), *out_len, *in_used and the check of the
+ * plaintext; -5 when the stream does not end inside in_len (nothing consumed: the adapter gathers more input);
+ * -3 (Z_DATA_ERROR) with the reference's strm->msg text in *msg; negative ZNG_ROCM_E* on a device failure. */
+int    zng_rocm_hook_inflate(zng_rocm_hook *h, const uint8_t *in, size_t in_len, int check, uint32_t *check_value,
+                             const uint8_t **out, size_t *out_len, size_t *in_used, const char **msg);
+
 /* ---- measurement hooks --------------------------------------------------
  * Between trace_begin and trace_end every (sampled) launch of the DOMINANT kernel of a *_dev entry point (the
  * streaming kernel, not its finalize step) carries a pair of HIP events attached to its own dispatch

@@ -150,6 +150,10 @@ int inflate_resolve_batch(const uint32_t *d_tokens, const uint8_t *d_literals, s
                           size_t nsegs, uint16_t *sym, const uint64_t *d_seg_dst, const uint64_t *d_seg_end,
                           const void *d_streams, size_t nstreams, hipStream_t st);
 
+// inflate_resolve.hip: host token stream -> plaintext at d_dst; synchronises `st`
+int inflate_tokens_to_device(const zng_rocm_inflate_tokens *tk, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
+                             hipStream_t st);
+
 // checksum.hip: one streaming pass (+ finalize) over device-resident bytes.  d_dst != nullptr = fold_copy.  When a
 // d_seed_* pointer is given, that checksum's seed is read ON THE DEVICE from it at finalize time (the word an earlier
 // launch on the same stream wrote) instead of from the scalar argument.

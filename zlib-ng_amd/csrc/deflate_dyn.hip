@@ -69,7 +69,7 @@ static inline size_t seg_d16_entries(uint32_t bytes) { return (((size_t)bytes + 
 // the HBM latency of the fetch is hidden behind a whole batch of searching.
 __global__ __launch_bounds__(kRowBatch)
 void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restrict__ bm_base, uint16_t *__restrict__ d16_base,
-                    uint32_t *__restrict__ hist_out, uint32_t max_cand) {
+                    uint32_t *__restrict__ hist_out, uint32_t max_cand, unsigned long long *__restrict__ stamp_out) {
     __shared__ RowShared sh;
 
     const SegJob job = jobs[blockIdx.x];
@@ -155,6 +155,11 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
         } else if (r.kind == 1u) {
             atomicAdd(&sh.hist_l[sh.ring[p & (kRingBytes - 1u)]], 1u);
         }
+#ifdef ZR_ROWS_STAMPS
+        if (lane == 0) sh.stamps[t >> 6][8] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 3 && stamp_out && lane < 9 && P >= first + 64u * kRowBatch && P < first + 96u * kRowBatch)
+            stamp_out[(((P - first) / kRowBatch - 64u) * kRowWaves + (uint32_t)(t >> 6)) * 9u + (uint32_t)lane] = sh.stamps[t >> 6][lane];
+#endif
     }
     __syncthreads();
     if (t < kHistWords) hist_out[(size_t)blockIdx.x * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];
@@ -743,6 +748,8 @@ static inline size_t seg_slot_bytes(uint32_t n) {
     return (((size_t)n * 9 + 7) / 8 + 1024 + 3) & ~(size_t)3;
 }
 
+unsigned long long *g_rows_stamps = nullptr;      // ZR_ROWS_STAMPS builds: device buffer of phase time stamps
+
 // candidates looked at per position, per level: the row form of max_chain_length (deflate.c:142-168: 4, 6, 24, 32, 128
 // links at levels 2..6); level 1 = deflate_quick's single probe (deflate_quick.c:89-97)
 static const uint32_t kLevelCand[10] = {0, 1, 2, 3, 6, 8, 16, 16, 16, 16};
@@ -806,7 +813,7 @@ static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, siz
     for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
     ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
 
-    ZR_LAUNCH_TRACED(lz_rows_kernel, dim3((unsigned)nseg), dim3(kRowBatch), st, d_jobs, d_bm, d_d16, d_hist, kLevelCand[level] | (getenv("ZR_EXP") ? (uint32_t)atoi(getenv("ZR_EXP")) << 8 : 0u));
+    ZR_LAUNCH_TRACED(lz_rows_kernel, dim3((unsigned)nseg), dim3(kRowBatch), st, d_jobs, d_bm, d_d16, d_hist, kLevelCand[level], g_rows_stamps);
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_bm, d_d16, d_hist, d_seg_len);
     ZR_HIP(hipGetLastError());
@@ -825,6 +832,12 @@ static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, siz
 using namespace zr;
 
 extern "C" {
+
+#ifdef ZR_ROWS_STAMPS
+// diagnostic builds only (tools/micro/rows_stamps.sh): where lz_rows_kernel writes its phase time stamps
+// (32 batches x 16 waves x 9 stamps of workgroup 3)
+void zng_rocm_debug_rows_stamps(void *d_buf) { g_rows_stamps = (unsigned long long *)d_buf; }
+#endif
 
 size_t zng_rocm_deflate_bound(size_t source_len) {
     const size_t nseg = source_len ? (source_len + kSegBytesMin - 1) / kSegBytesMin : 1;     // the most there can be

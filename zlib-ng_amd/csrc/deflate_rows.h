@@ -46,6 +46,12 @@ constexpr uint32_t kCostMax = 15u * kCostBit;
 constexpr uint32_t kCostInf = 0xffffffffu;
 constexpr int      kRefreshBatches = 4;            // symbol costs are recomputed from the histogram this often
 
+#ifdef ZR_ROWS_STAMPS
+#define ZR_STAMP(k) do { if (lane == 0) sh->stamps[wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZR_STAMP(k) do { } while (0)
+#endif
+
 struct RowShared {
     uint8_t  ring[kRingBytes + kRingMirror];
     uint16_t pos[kRows * kRowEnt];
@@ -56,6 +62,9 @@ struct RowShared {
     uint16_t cost_l[288], cost_d[32];   // current estimate, units of 1/16 bit, without extra bits
     uint32_t tot_l, tot_d;
     uint32_t cover;                     // absolute: first position not yet produced (carried across batches)
+#ifdef ZR_ROWS_STAMPS
+    unsigned long long stamps[kRowWaves][10];
+#endif
 };
 static_assert(sizeof(RowShared) <= 160 * 1024, "RowShared must fit the CU's LDS");
 
@@ -180,6 +189,35 @@ __device__ __forceinline__ uint32_t rows_candidates(const uint2 T, const uint4 P
     return m;
 }
 
+// One step of the backward recurrence at region position I (compile-time, so that every lane select is an immediate):
+//   cost[I] = min(literal + cost[I + 1], min over l in 4..min(len, 64) of match(l) + cost[I + l], the full length if > 64)
+// W: lane j holds cost[I + 1 + j] << 6; LC: lane j holds the cost of length j + 1, shifted, with j in its low six bits, so
+// the minimum carries the chosen length; the literal rides along as candidate lane 0.
+template <int I>
+__device__ __forceinline__ void rows_dp_step(uint32_t L, uint32_t LIT6, uint32_t DC6, uint32_t FULL, uint32_t LC, int lane,
+                                             uint32_t lim, uint32_t &W, uint32_t &CH, uint32_t &cnext6) {
+    const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)L, I);
+    const uint32_t sLit6 = (uint32_t)__builtin_amdgcn_readlane((int)LIT6, I);
+    const uint32_t sDc6 = (uint32_t)__builtin_amdgcn_readlane((int)DC6, I);
+    const uint32_t top = sL < 64u ? sL : 64u;
+    uint32_t v = (uint32_t)lane < top ? W + LC + sDc6 : kCostInf;       // lanes 0..2 of LC are out of reach
+    v = lane == 0 ? sLit6 + cnext6 : v;
+    uint32_t m = wave_min_u32(v);
+    uint32_t bl = (m & 63u) + 1u;
+    m &= ~63u;
+    if (sL > 64u) {                                       // the full length reaches beyond the region: a credit per byte
+        const uint32_t cf6 = (((uint32_t)__builtin_amdgcn_readlane((int)FULL, I) + kCostBias -
+                               kCostBeta * ((uint32_t)I + sL - lim)) << 6) + sDc6;
+        if (cf6 < m) {
+            m = cf6;
+            bl = sL;
+        }
+    }
+    cnext6 = m;
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(CH) : "s"(bl), "n"(I));
+    W = wave_shift_up1(W, m);
+}
+
 // One batch of kRowBatch positions starting at P; the ring holds every byte of [max(P0, P - 32768), P + batch + kRingAhead)
 // that lies below n, P0 = the first position that was ever loaded.  Returns this lane's token; the region's token-start
 // mask goes to *starts.  `refresh`: recompute the symbol costs from the histogram first.
@@ -195,14 +233,17 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
     uint32_t row, tag;
     row_key(val, row, tag);
 
+    ZR_STAMP(0);
     // A. the row as it is in front of this batch
     const uint2 TA = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
     const uint4 PA = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
     __syncthreads();
     const uint32_t cover_in = sh->cover;                 // written by the previous batch in front of this barrier
     if (refresh) rows_refresh_costs(sh, t);              // its readers come behind the insert turns' barriers
+    ZR_STAMP(1);
     // B. insert, waves in position order
     rows_insert(sh, can, row, tag, p, wave);
+    ZR_STAMP(2);
     // C. the row with the batch in it: only entries inside the batch and below p are news
     const uint2 TC = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
     const uint4 PC = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
@@ -210,7 +251,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
     // ---- longest match at every position --------------------------------------------------------------------------
     const uint32_t maxlen = p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u;
     uint32_t best = 3, dist = 0;                         // a match must reach WANT_MIN_MATCH to count
-    if (can && !(max_cand & 0x200u)) {
+    if (can) {
         const uint32_t back = p - P0;                    // bytes of history the ring really holds
         const uint32_t dmax = back < kLzMaxDist ? back : kLzMaxDist;
         uint32_t dC[4], dA[4];
@@ -222,7 +263,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         for (int j = 0; j < 4; ++j) mine[j] = ring_u32(ring, pi + 4u * j);
         uint32_t tail_off = 0, want_tail = mine[0];      // the 4 bytes that end at `best` must agree (match_tpl.h:141-173)
         bool done = false;
-        uint32_t budget = max_cand & 0xffu;
+        uint32_t budget = max_cand;
 
         auto consider = [&](uint32_t d) __attribute__((always_inline)) {
             const uint32_t ci = (pi - d) & (kRingBytes - 1u);
@@ -275,6 +316,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
             best = ring_common_prefix(ring, pi, (pi - dist) & (kRingBytes - 1u), best, maxlen);
     }
 
+    ZR_STAMP(3);
     // ---- shortest-path parse of this wave's region [w0, w0 + lim) ---------------------------------------------------
     const uint32_t w0 = P + 64u * (uint32_t)wave;
     const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);        // wave-uniform
@@ -294,37 +336,20 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         LC = (uint32_t)lane < 3u ? 0x7fffffffu : (((sh->cost_l[sy] + kCostBit * eb) << 6) | (uint32_t)lane);
     }
     uint32_t CH = 1u;                                    // lane i: length of the token the best path takes at position i
-    if (max_cand & 0x100u) CH = L ? L : 1u;             // TIMING EXPERIMENT: greedy, no parse
-    else {
-        uint32_t W = (kCostBias - kCostBeta * (uint32_t)lane) << 6;     // lane j: cost[i + 1 + j] << 6, i = lim - 1
-        uint32_t cnext = kCostBias;
-        for (int i = (int)lim - 1; i >= 0; --i) {
-            const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)L, i);
-            uint32_t cbest = (uint32_t)__builtin_amdgcn_readlane((int)LIT, i) + cnext, bl = 1u;
-            if (sL >= kLzMinMatch) {
-                const uint32_t sDc = (uint32_t)__builtin_amdgcn_readlane((int)DC, i);
-                const uint32_t top = sL < 64u ? sL : 64u;
-                const uint32_t v = (uint32_t)lane < top ? W + LC : kCostInf;
-                const uint32_t m = wave_min_u32(v);
-                const uint32_t c = (m >> 6) + sDc;
-                if (c < cbest) {
-                    cbest = c;
-                    bl = (m & 63u) + 1u;
-                }
-                if (sL > 64u) {                           // the full length reaches beyond the region: a credit per byte
-                    const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)FULL, i) + sDc + kCostBias -
-                                        kCostBeta * ((uint32_t)i + sL - lim);
-                    if (cf < cbest) {
-                        cbest = cf;
-                        bl = sL;
-                    }
-                }
-            }
-            cnext = cbest;
-            CH = lane == i ? bl : CH;
-            W = wave_shift_up1(W, cbest << 6);
-        }
+    if (lim) {
+        // positions at or beyond lim (the segment's end inside this region) cost what the credit gives: the recurrence then
+        // needs no special case for a short region and runs its 64 steps unrolled, every lane index an immediate
+        const uint32_t LIT6 = ((uint32_t)lane < lim ? LIT : kCostBeta) << 6, DC6 = DC << 6;
+        const uint32_t Lr = (uint32_t)lane < lim ? L : 0u;
+        uint32_t W = (kCostBias - kCostBeta * (64u + (uint32_t)lane - lim)) << 6;      // lane j: cost[64 + j] << 6
+        uint32_t cnext6 = (kCostBias - kCostBeta * (64u - lim)) << 6;
+#define ZR_DP1(I) rows_dp_step<I>(Lr, LIT6, DC6, FULL, LC, lane, lim, W, CH, cnext6);
+#define ZR_DP8(I) ZR_DP1(I + 7) ZR_DP1(I + 6) ZR_DP1(I + 5) ZR_DP1(I + 4) ZR_DP1(I + 3) ZR_DP1(I + 2) ZR_DP1(I + 1) ZR_DP1(I)
+        ZR_DP8(56) ZR_DP8(48) ZR_DP8(40) ZR_DP8(32) ZR_DP8(24) ZR_DP8(16) ZR_DP8(8) ZR_DP8(0)
+#undef ZR_DP8
+#undef ZR_DP1
     }
+    ZR_STAMP(4);
     // exit map: where does the path through position i leave the region?  pointer doubling over next[i] = i + CH[i]
     {
         uint32_t J = (uint32_t)lane + CH;
@@ -338,6 +363,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
     }
     __syncthreads();
 
+    ZR_STAMP(5);
     // stitch: follow the exits of the regions in front of this one from where the previous batch ended
     const uint32_t nrel = n - P;                          // n > P for every batch that runs
     uint32_t s = cover_in - P;
@@ -345,6 +371,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         if (s < 64u * (uint32_t)(r + 1) && s < nrel)
             s = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->exitmap[s]);
     }
+    ZR_STAMP(6);
     unsigned long long mask = 0;
     {
         uint32_t q = s - 64u * (uint32_t)wave;            // s >= 64 * wave by construction
@@ -356,6 +383,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         if (wave == kRowWaves - 1 && lane == 0)
             sh->cover = P + (s < 64u * (uint32_t)(wave + 1) && s < nrel ? 64u * (uint32_t)wave + q : s);
     }
+    ZR_STAMP(7);
     *starts = mask;
     RowsToken r;
     r.kind = 0;

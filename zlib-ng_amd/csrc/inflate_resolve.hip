@@ -331,6 +331,52 @@ int zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntokens
                         window_len, true, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+namespace zr {
+// host token stream -> plaintext at d_dst (tk->out_len bytes): uploads tokens | segs | literals, resolves against the
+// optional device-resident window, synchronises the stream (the staging buffers are released behind it)
+int inflate_tokens_to_device(const zng_rocm_inflate_tokens *tkp, const uint8_t *d_window, uint32_t window_len,
+                             uint8_t *d_dst, hipStream_t st) {
+    const zng_rocm_inflate_tokens &tk = *tkp;
+    int rc = ZNG_ROCM_OK;
+    if (tk.out_len) {
+        // one device allocation: tokens | segs | literals | symbols
+        const size_t tok_b = (tk.ntokens * 4 + 255) & ~(size_t)255;
+        const size_t seg_b = ((tk.nsegs + 1) * 24 + 255) & ~(size_t)255;
+        const size_t lit_b = (tk.nliterals + 255) & ~(size_t)255;
+        const size_t sym_b = ((size_t)tk.out_len + (size_t)kCtx) * 2;          // + the window's symbols in front
+        uint8_t *d = nullptr;
+        if (hipMalloc(&d, tok_b + seg_b + lit_b + sym_b) != hipSuccess) {
+            set_error("device allocation for the token stream failed");
+            return ZNG_ROCM_ENOMEM;
+        }
+        hipError_t e = hipMemcpyAsync(d, tk.tokens, tk.ntokens * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + tok_b, tk.segs, (tk.nsegs + 1) * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && tk.nliterals)
+            e = hipMemcpyAsync(d + tok_b + seg_b, tk.literals, tk.nliterals, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            set_error("H2D of the token stream failed: %s", hipGetErrorString(e));
+            rc = ZNG_ROCM_EHIP;
+        } else {
+            rc = zng_rocm_inflate_resolve_window_dev((const uint32_t *)d, tk.ntokens, d + tok_b + seg_b, tk.nliterals,
+                                                     (const uint64_t *)(d + tok_b), tk.nsegs,
+                                                     (uint16_t *)(d + tok_b + seg_b + lit_b), d_dst, tk.out_len,
+                                                     d_window, window_len, st);
+        }
+        // the host buffers and the device workspace are released after the stream drained
+        if (hipStreamSynchronize(st) != hipSuccess && rc == ZNG_ROCM_OK) {
+            set_error("stream synchronize failed");
+            rc = ZNG_ROCM_EHIP;
+        }
+        (void)hipFree(d);
+    }
+    return rc;
+}
+}  // namespace zr
+
+extern "C" {
+
 int zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                 uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
@@ -373,39 +419,7 @@ int zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_
         return -5;
     }
     if (status < 0) set_error("%s", tk.msg);
-    int rc = ZNG_ROCM_OK;
-    if (tk.out_len) {
-        // one device allocation: tokens | segs | literals | symbols
-        const size_t tok_b = (tk.ntokens * 4 + 255) & ~(size_t)255;
-        const size_t seg_b = ((tk.nsegs + 1) * 24 + 255) & ~(size_t)255;
-        const size_t lit_b = (tk.nliterals + 255) & ~(size_t)255;
-        const size_t sym_b = ((size_t)tk.out_len + (size_t)kCtx) * 2;          // + the window's symbols in front
-        uint8_t *d = nullptr;
-        if (hipMalloc(&d, tok_b + seg_b + lit_b + sym_b) != hipSuccess) {
-            zng_rocm_inflate_tokens_free(&tk);
-            set_error("device allocation for the token stream failed");
-            return ZNG_ROCM_ENOMEM;
-        }
-        hipError_t e = hipMemcpyAsync(d, tk.tokens, tk.ntokens * 4, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(d + tok_b, tk.segs, (tk.nsegs + 1) * 24, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && tk.nliterals)
-            e = hipMemcpyAsync(d + tok_b + seg_b, tk.literals, tk.nliterals, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
-            set_error("H2D of the token stream failed: %s", hipGetErrorString(e));
-            rc = ZNG_ROCM_EHIP;
-        } else {
-            rc = zng_rocm_inflate_resolve_window_dev((const uint32_t *)d, tk.ntokens, d + tok_b + seg_b, tk.nliterals,
-                                                     (const uint64_t *)(d + tok_b), tk.nsegs,
-                                                     (uint16_t *)(d + tok_b + seg_b + lit_b), d_dst, tk.out_len,
-                                                     d_window, window_len, st);
-        }
-        // the host buffers and the device workspace are released after the stream drained
-        if (hipStreamSynchronize(st) != hipSuccess && rc == ZNG_ROCM_OK) {
-            set_error("stream synchronize failed");
-            rc = ZNG_ROCM_EHIP;
-        }
-        (void)hipFree(d);
-    }
+    const int rc = inflate_tokens_to_device(&tk, d_window, window_len, d_dst, st);
     zng_rocm_inflate_tokens_free(&tk);
     return rc != ZNG_ROCM_OK ? rc : status;
 }
