@@ -17,6 +17,9 @@ uint32_t crc32_fold_final_rocm(struct crc32_fold_s *crc);
 /* init_functable() hands over the CPU tier it has chosen so far, before it installs the slots above */
 void rocm_remember_cpu_tier(uint32_t (*adler32)(uint32_t, const uint8_t *, size_t),
                             uint32_t (*crc32)(uint32_t, const uint8_t *, size_t));
+/* ... and the rest of arch/rocm uses it where the device has to be left out (rocm_deflate.c, rocm_inflate.c) */
+uint32_t rocm_cpu_adler32(uint32_t adler, const uint8_t *buf, size_t len);
+uint32_t rocm_cpu_crc32(uint32_t crc, const uint8_t *buf, size_t len);
 #endif
 
 #endif

@@ -36,6 +36,9 @@ void Z_INTERNAL rocm_remember_cpu_tier(uint32_t (*adler32)(uint32_t, const uint8
     cpu_crc32 = crc32;
 }
 
+Z_INTERNAL uint32_t rocm_cpu_adler32(uint32_t adler, const uint8_t *buf, size_t len) { return cpu_adler32(adler, buf, len); }
+Z_INTERNAL uint32_t rocm_cpu_crc32(uint32_t crc, const uint8_t *buf, size_t len) { return cpu_crc32(crc, buf, len); }
+
 Z_INTERNAL uint32_t adler32_rocm(uint32_t adler, const uint8_t *buf, size_t len) {
     uint32_t out;
     if (len >= ROCM_MIN_BYTES && zng_rocm_adler32_try(adler, buf, len, &out) == ZNG_ROCM_OK)

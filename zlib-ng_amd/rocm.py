@@ -113,6 +113,17 @@ _PROTOS = {
                                          C.c_void_p]),
     "zng_rocm_uncompress2_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
                                            C.c_int, C.c_void_p]),
+    "zng_rocm_hook_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "zng_rocm_hook_destroy": (None, [C.c_void_p]),
+    "zng_rocm_hook_reset": (C.c_int, [C.c_void_p]),
+    "zng_rocm_hook_set_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zng_rocm_hook_get_history": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "zng_rocm_hook_deflate_bound": (C.c_size_t, [C.c_size_t]),
+    "zng_rocm_hook_deflate_block": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int,
+                                              C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zng_rocm_hook_inflate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_char_p)]),
     "zng_rocm_trace_begin": (C.c_int, [C.c_int]),
     "zng_rocm_trace_end": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "zng_rocm_adler32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_int64]),
