@@ -347,6 +347,18 @@ int  zng_rocm_inflate_raw_ex(const uint8_t *src, size_t src_len, uint8_t *d_dst,
 int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                  uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
+/* ONE large raw stream that is ALREADY in device memory, inflated on the device: block starts are found on the device
+ * (dynamic headers the decoder would accept, sync-flush markers), the stream is cut there into parts of >= 34 KiB, one
+ * wavefront decodes each part into 16-bit symbols (inffast_tpl.h:151-298 with the history still unknown), the parts are
+ * chained from bit 0 and the context chain of zng_rocm_inflate_resolve_dev turns the symbols into bytes.  The host only
+ * sorts a few thousand candidates and walks the chain.  Streams that offer nothing to cut at (fixed-Huffman blocks
+ * only) and every irregular stream go to the sequential decoder, so status and message are always the
+ * reference's.  Returns as zng_rocm_inflate_raw_window; synchronous. */
+int  zng_rocm_inflate_large_dev(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                                uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
+/* parts on the chain of the calling thread's last zng_rocm_inflate_large_dev (0: the sequential decoder did it) */
+int  zng_rocm_inflate_large_last_parts(void);
+
 /* Many independent raw streams at once: `nthreads` host threads (<= 0: as many as the host gives us) take the jobs in
  * order, each decoding on the host and resolving on the device on its own HIP stream, so that the sequential decode
  * -- where an inflate spends its time -- runs on all the cores the caller allows while the device work of one stream

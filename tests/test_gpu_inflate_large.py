@@ -1,0 +1,110 @@
+"""ONE large raw deflate stream inflated on the device (zng_rocm_inflate_large_dev): block starts found
+on the device, one wavefront per part, symbols resolved by the context chain of inflate_resolve.hip.  The loop replaced is
+inflate_fast (inffast_tpl.h:151-298) with the headers around it (inflate.c:735-917).  Oracle: the plaintext (inflate output
+of a valid stream is unique), CPython's zlib for the streams, the sequential decoder's status / message for damaged ones."""
+import importlib
+import zlib
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    zr = importlib.import_module("zlib-ng_amd")
+    zr.init(0)
+    return torch, importlib.import_module("zlib-ng_amd.inflate"), importlib.import_module("zlib-ng_amd.deflate")
+
+
+def _raw(plain, level, zdict=None):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, zdict) if zdict else \
+        zlib.compressobj(level, zlib.DEFLATED, -15)
+    return c.compress(plain) + c.flush()
+
+
+@pytest.mark.parametrize("level,mib", [(6, 32), (1, 16), (9, 8)])
+def test_cpython_streams_are_cut_and_decoded_on_the_device(mods, level, mib):
+    torch, inf, _ = mods
+    plain = synth.silesia_like(mib << 20, seed=0xA11CE + level)
+    comp = _raw(plain.tobytes(), level)
+    src = torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()
+    dst = torch.zeros(plain.size + 64, dtype=torch.uint8, device="cuda")
+    st, n, used, parts = inf.inflate_large_dev(src, dst)
+    assert (st, n, used) == (1, plain.size, len(comp))
+    zr = importlib.import_module("zlib-ng_amd")
+    assert parts >= 8, (parts, zr.rocm.lib().zng_rocm_last_error())      # really cut into parts, not the sequential decoder
+    assert torch.equal(dst[:n].cpu(), torch.from_numpy(plain))
+    assert int(dst[n:].max()) == 0                        # nothing written behind the end
+
+
+def test_own_level6_stream_with_sync_markers(mods):
+    torch, inf, dfl = mods
+    plain = synth.silesia_like(48 << 20, seed=77)
+    src_plain = torch.from_numpy(plain).cuda()
+    comp, clen = dfl.deflate_dev(src_plain, level=6)
+    dst = torch.zeros(plain.size, dtype=torch.uint8, device="cuda")
+    st, n, used, parts = inf.inflate_large_dev(comp[:clen].contiguous(), dst)
+    assert (st, n, used) == (1, plain.size, clen) and parts >= 8
+    assert torch.equal(dst, src_plain)
+
+
+def test_history_in_front_of_the_stream(mods):
+    torch, inf, _ = mods
+    plain = synth.silesia_like(8 << 20, seed=5).tobytes()
+    zdict = plain[-20000:]                                # the stream's first matches reach into the dictionary
+    comp = _raw(plain, 6, zdict)
+    src = torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()
+    win = torch.from_numpy(np.frombuffer(zdict, dtype=np.uint8).copy()).cuda()
+    dst = torch.zeros(len(plain), dtype=torch.uint8, device="cuda")
+    st, n, used, parts = inf.inflate_large_dev(src, dst, window=win)
+    assert (st, n, used) == (1, len(plain), len(comp)) and parts >= 2
+    assert dst.cpu().numpy().tobytes() == plain
+    # without the dictionary the same stream reaches too far back: the sequential decoder reports it
+    st2, _, _, parts2 = inf.inflate_large_dev(src, dst)
+    assert st2 == -3 and parts2 == 0
+
+
+def test_irregular_streams_fall_back_with_the_references_answer(mods):
+    torch, inf, _ = mods
+    plain = synth.silesia_like(8 << 20, seed=9).tobytes()
+    comp = bytearray(_raw(plain, 6))
+    dst = torch.zeros(len(plain), dtype=torch.uint8, device="cuda")
+    # truncated: input ends before the final block
+    src = torch.from_numpy(np.frombuffer(bytes(comp[:len(comp) // 2]), dtype=np.uint8).copy()).cuda()
+    st, n, used, parts = inf.inflate_large_dev(src, dst)
+    assert st == -5 and parts == 0
+    assert dst[:n].cpu().numpy().tobytes() == plain[:n] and n > 0
+    # a flipped bit in the middle: same status as the sequential decoder
+    comp[len(comp) // 2] ^= 0x10
+    bad = bytes(comp)
+    ref = inf.decode_tokens(bad)
+    src = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).cuda()
+    st, n, used, parts = inf.inflate_large_dev(src, dst)
+    assert st == ref.status and n == ref.out_len
+    if ref.status == 1:                                   # the damage left a valid stream: same bytes as the sequential decoder
+        assert used == ref.in_used and torch.equal(dst[:n], inf.resolve_dev(ref))
+    else:
+        assert parts == 0
+    # a fixed-Huffman-only stream offers nothing to cut at: sequential, still correct
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    fixed = c.compress(plain) + c.flush()
+    src = torch.from_numpy(np.frombuffer(fixed, dtype=np.uint8).copy()).cuda()
+    st, n, used, parts = inf.inflate_large_dev(src, dst)
+    assert (st, n, used, parts) == (1, len(plain), len(fixed), 0)
+    assert dst.cpu().numpy().tobytes() == plain
+
+
+def test_small_and_highly_compressible_streams(mods):
+    torch, inf, _ = mods
+    for plain in (b"hello world " * 10, bytes(64 << 20), synth.silesia_like(300 << 10, seed=3).tobytes()):
+        comp = _raw(plain, 6)
+        src = torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()
+        dst = torch.zeros(len(plain), dtype=torch.uint8, device="cuda")
+        st, n, used, _ = inf.inflate_large_dev(src, dst)
+        assert (st, n, used) == (1, len(plain), len(comp))
+        assert dst.cpu().numpy().tobytes() == plain

@@ -69,6 +69,10 @@ enum ScratchSlot {
     kScrFrameWords,         // device: per-stream words of the many-stream framing entry points (framing_dev.hip)
     kScrFrameJobs,          // device: FrameJob[]
     kScrFrameJobsHost,      // pinned
+    kScrLargeCand,          // device: candidate block starts of zng_rocm_inflate_large_dev
+    kScrLargeParts,         // device: jobs | starts | results | symbol slots of the parts
+    kScrLargeRetry,         // device: worst-case slots of the parts that overflowed theirs
+    kScrLargeSym,           // device: segs | copies | the stream's symbol array
     kScrCount
 };
 

@@ -25,4 +25,8 @@ enum InflateMsg : uint32_t {
 // one wavefront per job; d_jobs and d_results are device memory (results: 4 words per job)
 int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, hipStream_t stream);
 
+// the parts of ONE large stream, 16-bit symbols out (inflate_large.hip); results: 8 words per part
+int launch_inflate_parts_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, const unsigned long long *d_starts,
+                                hipStream_t stream);
+
 }  // namespace zr

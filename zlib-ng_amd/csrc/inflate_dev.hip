@@ -23,12 +23,29 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "context.h"
 #include "deflate_dev.h"
 #include "inflate_dev.h"
 
 namespace zr {
 
+// Diagnostic builds (-DZR_INFLATE_BOUNDS, tools/micro/inflate_bounds.sh): every index the table builder computes from
+// stream data is checked against the array it goes into; a violation is counted (zng_rocm_debug_inflate_bounds()) and the
+// index clamped.  Round 2's aperture violation was traced to addressing, not to an index; this build is the
+// evidence that no index leaves its array on the mutated-stream corpus either.
+#ifdef ZR_INFLATE_BOUNDS
+__device__ unsigned int g_inflate_bounds_violations;
+__device__ __forceinline__ uint32_t zr_idx(uint32_t i, uint32_t n) {
+    if (i < n) return i;
+    atomicAdd(&g_inflate_bounds_violations, 1u);
+    return 0;
+}
+#define ZR_IDX(i, n) zr_idx((uint32_t)(i), (uint32_t)(n))
+#else
+#define ZR_IDX(i, n) (i)
+#endif
 
 // Table entry, 16 bits: code length in bits 0-3, SYMBOL in bits 4-15 (literal/length 0..287, distance 0..31, code-length
 // symbol 0..18).  Base values and extra-bit counts are arithmetic in the symbol (length_of / distance_of), so nothing
@@ -42,7 +59,7 @@ constexpr int kLitRoot = 10, kDistRoot = 9, kClRoot = 7;
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 constexpr int kCodeLit = 0, kCodeDist = 1, kCodeCl = 2;
 
-template <int RING>
+template <int RING, typename T>
 struct InflateLds {
     uint16_t lit[1 << kLitRoot];
     uint32_t dist[1 << kDistRoot];      // wide entries: code length | extra bits << 4 | base distance << 8 (wide_distance)
@@ -51,7 +68,7 @@ struct InflateLds {
     uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[32];
     uint8_t  lens[320 + 8];
     uint8_t  cl_lens[24];
-    uint8_t  ring[RING] __attribute__((aligned(16)));
+    T        ring[RING] __attribute__((aligned(16)));
 };
 
 // base values / extra bits of the length and distance symbols (RFC 1951 3.2.5; inftrees.c:38-49 hold the same numbers)
@@ -90,13 +107,13 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // primary table, one entry per lane per pass, each found by the canonical comparison "code - first[L] < count[L]".
 // Codes longer than the root get a kLong entry; the decode loop resolves those with the same comparison (they are the
 // rare symbols by construction).  Returns 0, or 1 for an invalid set.
-template <int RING>
-__device__ __forceinline__ int build_code(InflateLds<RING> &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
+template <typename LDS>
+__device__ __forceinline__ int build_code(LDS &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
                           uint16_t *sorted, int lane) {
     uint32_t *cnt = L.cnt[which], *first = L.first[which], *offs = L.offs[which];
     if (lane < 16) cnt[lane] = 0;
     wave_sync();
-    for (int s = lane; s < n; s += 64) atomicAdd(&cnt[lens[s]], 1u);
+    for (int s = lane; s < n; s += 64) atomicAdd(&cnt[ZR_IDX(lens[s], 16)], 1u);
     wave_sync();
     const uint32_t mine = lane < 16 ? cnt[lane] : 0u;
     int left = 1, max = 0;
@@ -135,9 +152,9 @@ __device__ __forceinline__ int build_code(InflateLds<RING> &L, int which, const 
             const uint32_t lu = (uint32_t)__builtin_amdgcn_readlane((int)l, f);
             const bool hit = active && l == lu;
             const unsigned long long same = __ballot(hit);
-            const uint32_t at = uni(L.run[lu]);
-            if (hit) sorted[at + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull))] = (uint16_t)s;
-            if (lane == f) L.run[lu] = at + (uint32_t)__builtin_popcountll(same);
+            const uint32_t at = uni(L.run[ZR_IDX(lu, 16)]);
+            if (hit) sorted[ZR_IDX(at + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)), which == kCodeLit ? 288 : 32)] = (uint16_t)s;
+            if (lane == f) L.run[ZR_IDX(lu, 16)] = at + (uint32_t)__builtin_popcountll(same);
             active = active && !hit;
             m &= ~same;
             wave_sync();
@@ -151,7 +168,7 @@ __device__ __forceinline__ int build_code(InflateLds<RING> &L, int which, const 
         for (int len = 1; len <= top; ++len) {
             const uint32_t d = (rev >> (root - len)) - first[len];
             if (d < cnt[len]) {
-                ent = make_entry((uint32_t)len, sorted[offs[len] + d]);
+                ent = make_entry((uint32_t)len, sorted[ZR_IDX(offs[len] + d, which == kCodeLit ? 288 : 32)]);
                 break;
             }
         }
@@ -163,35 +180,47 @@ __device__ __forceinline__ int build_code(InflateLds<RING> &L, int which, const 
 }
 
 // A code longer than the root: the canonical comparison over the remaining lengths, wave-uniform.
-template <int RING>
-__device__ __forceinline__ uint32_t long_code(InflateLds<RING> &L, int which, int root, const uint16_t *sorted,
+template <typename LDS>
+__device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const uint16_t *sorted,
                                               unsigned long long hold) {
     const uint32_t rev15 = __builtin_bitreverse32((uint32_t)hold & 0x7fffu) >> 17;
     const int max = (int)uni(L.cnt[which][0]);
     for (int len = root + 1; len <= max; ++len) {
         const uint32_t d = (rev15 >> (15 - len)) - uni(L.first[which][len]);
-        if (d < uni(L.cnt[which][len])) return make_entry((uint32_t)len, uni(sorted[uni(L.offs[which][len]) + d]));
+        if (d < uni(L.cnt[which][len])) return make_entry((uint32_t)len, uni(sorted[ZR_IDX(uni(L.offs[which][len]) + d, which == kCodeLit ? 288 : 32)]));
     }
     return kBadMark;
 }
 
-template <int RING>
+// PART = false: a job is a whole stream, the output is bytes (the many-stream entry points).
+// PART = true (inflate_large.hip): a job is a PART of one large stream -- the decode starts at bit starts[job] of the
+// stream, in the middle of it, and runs until a block ends exactly on a later entry of `starts` (or the stream ends).
+// What lies in front of a part is not known while it is decoded, so the output is 16-bit SYMBOLS in the format of
+// inflate_resolve.hip: a byte, or 256 + k = "byte k of the 32 KiB in front of this part"; copies move symbols, so
+// unresolved references propagate by themselves, and the context chain of inflate_resolve.hip turns them into bytes.
+// Results per part: 8 words {symbols produced, end bit (lo, hi), status, message, furthest reach in front of the part,
+// index of the start it ended on, BFINAL seen}.
+template <int RING, bool PART>
 __global__ __launch_bounds__(64)
-void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njobs, uint32_t *__restrict__ results) {
+void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njobs, uint32_t *__restrict__ results,
+                            const unsigned long long *__restrict__ starts) {
+    typedef typename std::conditional<PART, uint16_t, uint8_t>::type T;
+    constexpr uint32_t E = 16u / (uint32_t)sizeof(T);   // elements per 16-byte store
     constexpr uint32_t M = RING - 1;
     constexpr uint32_t kFlushAt = RING / 2;              // unflushed bytes that trigger a flush
     constexpr uint32_t kNear = RING - 258;               // a source this close is still in the ring while the match is written
     // bytes not yet flushed never exceed kFlushAt + 16 + max(258, 1024); a match of 258 more must not overwrite them
     static_assert(kFlushAt + 16 + 1024 + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
-    __shared__ InflateLds<RING> L;
+    __shared__ InflateLds<RING, T> L;
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
     const InflateJobDev J = jobs[job];
     const ZR_GLOBAL uint8_t *const in = (const ZR_GLOBAL uint8_t *)J.in;
-    ZR_GLOBAL uint8_t *const out = (ZR_GLOBAL uint8_t *)J.out;
+    ZR_GLOBAL T *const out = (ZR_GLOBAL T *)J.out;
     const uint32_t in_len = (uint32_t)J.in_len, out_cap = (uint32_t)J.out_cap, dict_len = J.dict_len;
-    const uint32_t a0 = (uint32_t)((uintptr_t)J.out & 15u);            // ring slot of position p is (p + a0) & M
+    if (PART && out_cap == 0) return;                    // a part whose earlier result stands (inflate_large.hip reruns only some)
+    const uint32_t a0 = (uint32_t)((uintptr_t)J.out & 15u) / (uint32_t)sizeof(T);   // ring slot of position p is (p + a0) & M
 
     // ---- compressed words: 64 per fetch, the next 64 prefetched -------------------------------------------------
     const uint32_t lead = (uint32_t)((uintptr_t)J.in & 3u);
@@ -231,7 +260,15 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     auto bit_pos = [&]() __attribute__((always_inline)) -> unsigned long long {         // stream bits consumed so far
         return 32ull * wnext - 8ull * lead - cnt;
     };
-    seek(0);
+    uint32_t reach = 0, hit = 0xffffffffu;               // PART: furthest source in front of the part; the start it ended on
+    if (PART) {
+        const unsigned long long sb = starts[job];
+        seek((uint32_t)(sb >> 3));
+        hold >>= (uint32_t)(sb & 7ull);
+        cnt -= (uint32_t)(sb & 7ull);
+    } else {
+        seek(0);
+    }
 
     uint32_t op = 0, flushed = 0;
     uint32_t msg = kMsgNone;
@@ -241,24 +278,24 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     uint32_t litbuf = 0, npend = 0;
     auto dump = [&]() __attribute__((always_inline)) {
         if (npend) {
-            if ((uint32_t)lane < npend) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
+            if ((uint32_t)lane < npend) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (T)litbuf;
             npend = 0;
         }
     };
     // ring -> HBM: everything below `limit` (all of it when `final`), in aligned 16-byte stores
     auto flush = [&](uint32_t limit, bool final) __attribute__((always_inline)) {
-        if (((a0 + flushed) & 15u) && flushed < limit) {
-            uint32_t h = 16u - ((a0 + flushed) & 15u);
+        if (((a0 + flushed) & (E - 1u)) && flushed < limit) {
+            uint32_t h = E - ((a0 + flushed) & (E - 1u));
             if (h > limit - flushed) h = limit - flushed;
             if ((uint32_t)lane < h) out[flushed + lane] = L.ring[(a0 + flushed + lane) & M];
             flushed += h;
         }
-        const uint32_t chunks = (limit - flushed) >> 4;
+        const uint32_t chunks = (limit - flushed) / E;
         for (uint32_t c = (uint32_t)lane; c < chunks; c += 64) {
-            const uint32_t p = flushed + 16u * c;
+            const uint32_t p = flushed + E * c;
             *(ZR_GLOBAL u32x4_v *)(out + p) = *reinterpret_cast<const u32x4_v *>(&L.ring[(a0 + p) & M]);
         }
-        flushed += 16u * chunks;
+        flushed += E * chunks;
         if (final && flushed < limit) {
             if ((uint32_t)lane < limit - flushed) out[flushed + lane] = L.ring[(a0 + flushed + lane) & M];
             flushed = limit;
@@ -273,7 +310,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     auto service = [&]() __attribute__((always_inline)) {
         if (op > out_cap) {
             const uint32_t fit = npend - (op - out_cap);
-            if ((uint32_t)lane < fit) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (uint8_t)litbuf;
+            if ((uint32_t)lane < fit) L.ring[(a0 + op - npend + (uint32_t)lane) & M] = (T)litbuf;
             op = out_cap;
             npend = 0;
             msg = kMsgOutFull;
@@ -303,6 +340,21 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     // The control flow below is kept to single-exit loops with an error word (no jumps out of nested loops): every branch
     // here is wave-uniform, and anything else makes the compiler carry loop-exit conditions as lane masks through the
     // hot loop (the first version of this kernel executed 73 scalar instructions per symbol, most of them that).
+    // PART: does the block that just ended end exactly on a later start?  (binary search, wave-uniform)
+    auto block_end_stop = [&]() __attribute__((always_inline)) -> bool {
+        const unsigned long long b = bit_pos();
+        uint32_t lo = job + 1u, hi = njobs;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (starts[mid] < b) lo = mid + 1u;
+            else hi = mid;
+        }
+        if (lo < njobs && starts[lo] == b) {
+            hit = lo;
+            return true;
+        }
+        return false;
+    };
     bool last = false;
     while (!last && msg == kMsgNone) {
         if (cnt < 32) append();
@@ -338,7 +390,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                         const u32x4_unaligned v = *(const ZR_GLOBAL u32x4_unaligned *)src;
                         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) L.ring[(a0 + op + lo + k) & M] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                        for (int k = 0; k < 16; ++k) L.ring[(a0 + op + lo + k) & M] = (T)(uint8_t)(w[k >> 2] >> (8 * (k & 3)));
                     } else {
                         for (uint32_t k = 0; lo + k < piece; ++k) L.ring[(a0 + op + lo + k) & M] = src[k];
                     }
@@ -350,6 +402,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             if (len > avail) { msg = kMsgStarved; break; }
             if (n < len) { msg = kMsgOutFull; break; }
             seek(from + len);
+            if (PART && !last && block_end_stop()) break;
             continue;
         }
         if (type == 1) {
@@ -388,7 +441,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                 hold >>= nb;
                 cnt -= nb;
                 if (sym < 16) {
-                    if (lane == 0) L.lens[have] = (uint8_t)sym;
+                    if (lane == 0) L.lens[ZR_IDX(have, 320)] = (uint8_t)sym;
                     ++have;
                     continue;
                 }
@@ -410,7 +463,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     cnt -= 7;
                 }
                 if (have + rep > nlen + ndist) { msg = kMsgBitRepeat; break; }
-                for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L.lens[have + k] = (uint8_t)val;
+                for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L.lens[ZR_IDX(have + k, 320)] = (uint8_t)val;
                 have += rep;
             }
             if (msg != kMsgNone) break;
@@ -492,6 +545,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             hold >>= dxb;
             cnt -= dnb + dxb;
             if (dist > op + dict_len) { msg = kMsgTooFar; break; }                    // inffast_tpl.h:203-210
+            if (PART && dist > op && dist - op > reach) reach = dist - op;
             service();
             if (msg != kMsgNone) break;
             if (len > out_cap - op) { msg = kMsgOutFull; break; }
@@ -508,7 +562,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64)
                         L.ring[(a0 + op + i) & M] = L.ring[(a0 + (uint32_t)src0 + i) & M];
                 } else if (dist == 1) {
-                    const uint8_t v = L.ring[(a0 + (uint32_t)src0) & M];
+                    const T v = L.ring[(a0 + (uint32_t)src0) & M];
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64) L.ring[(a0 + op + i) & M] = v;
                 } else {
                     const float inv = 1.0f / (float)dist;
@@ -534,18 +588,37 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                         j = (uint32_t)r;
                     }
                     const int sp = src0 + (int)j;
-                    const uint8_t v = sp >= (int)flushed ? L.ring[(a0 + (uint32_t)sp) & M] : out[sp];
+                    T v;
+                    if (sp >= (int)flushed) v = L.ring[(a0 + (uint32_t)sp) & M];
+                    else if (PART && sp < 0) v = (T)(256 + 32768 + sp);      // a byte of the 32 KiB in front of this part
+                    else v = out[sp];
                     L.ring[(a0 + op + i) & M] = v;
                 }
             }
             op += len;
         }
+        if (PART && !last && msg == kMsgNone && block_end_stop()) break;
     }
     // bits that do not exist were consumed: whatever happened after that point, the stream ended early
     if (msg != kMsgOutFull) service();                   // (an out-of-room exit has clipped the run already)
-    if (bit_pos() > 8ull * in_len) msg = kMsgStarved;
+    // (a part keeps its out-of-room exit: inflate_large.hip gives it a larger slot and runs it again)
+    if (!(PART && msg == kMsgOutFull) && bit_pos() > 8ull * in_len) msg = kMsgStarved;
     wave_sync();
     flush(op, true);
+    if (PART) {
+        if (lane == 0) {
+            const unsigned long long b = bit_pos();
+            results[8 * job + 0] = op;
+            results[8 * job + 1] = (uint32_t)b;
+            results[8 * job + 2] = (uint32_t)(b >> 32);
+            results[8 * job + 3] = msg == kMsgNone ? (last ? 1u : 0u) : (msg == kMsgStarved || msg == kMsgOutFull) ? (uint32_t)-5 : (uint32_t)-3;
+            results[8 * job + 4] = msg;
+            results[8 * job + 5] = reach;
+            results[8 * job + 6] = hit;
+            results[8 * job + 7] = last ? 1u : 0u;
+        }
+        return;
+    }
     if (lane == 0) {
         const unsigned long long used = (bit_pos() + 7ull) >> 3;
         results[4 * job + 0] = op;
@@ -563,10 +636,19 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
         const char *r = getenv("ZNG_ROCM_INFLATE_RING");
         return r ? atoi(r) : 4096;
     }();
-    if (ring == 8192) ZR_LAUNCH_TRACED(inflate_streams_kernel<8192>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else if (ring == 16384) ZR_LAUNCH_TRACED(inflate_streams_kernel<16384>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else if (ring == 32768) ZR_LAUNCH_TRACED(inflate_streams_kernel<32768>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
-    else ZR_LAUNCH_TRACED(inflate_streams_kernel<4096>, dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results);
+    if (ring == 8192) ZR_LAUNCH_TRACED((inflate_streams_kernel<8192, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
+    else if (ring == 16384) ZR_LAUNCH_TRACED((inflate_streams_kernel<16384, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
+    else if (ring == 32768) ZR_LAUNCH_TRACED((inflate_streams_kernel<32768, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
+    else ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
+// the parts of ONE large stream (inflate_large.hip): d_starts = sorted start bits, one per job; results: 8 words per part
+int launch_inflate_parts_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, const unsigned long long *d_starts,
+                                hipStream_t st) {
+    if (!njobs) return ZNG_ROCM_OK;
+    ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, true>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }
@@ -576,6 +658,14 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
 using namespace zr;
 
 extern "C" {
+
+#ifdef ZR_INFLATE_BOUNDS
+unsigned int zng_rocm_debug_inflate_bounds(void) {
+    unsigned int v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(zr::g_inflate_bounds_violations), sizeof v);
+    return v;
+}
+#endif
 
 const char *zng_rocm_inflate_message(uint32_t id) {
     static const char *const text[kMsgCount] = {

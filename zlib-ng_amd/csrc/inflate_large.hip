@@ -1,0 +1,547 @@
+// inflate_large.hip -- ONE large raw deflate stream inflated on the device (BASELINE.json configs[2]).
+//
+// inflate_fast (inffast_tpl.h:53-318) is a serial bit parse: where a code starts depends on every code before it, and a
+// block header carries no marker.  inflate_dev.hip therefore needs many streams to fill the chip (one wavefront each).
+// This file cuts ONE stream into parts the same kernel can take -- the scheme of inflate_threads.cpp (pugz / rapidgzip),
+// with the device in place of the host threads:
+//   F1 find_headers_kernel      every BIT position of the stream is tested for the start of a dynamic block the decoder
+//        would accept, cheap tests first: BTYPE / HLIT / HDIST in range (inflate.c:808-813), the code-length code complete
+//        (inftrees.c:126-131; a Kraft sum over the 3-bit fields, three fields per table lookup).  About 1 position in
+//        10^3 is left.  Also: the byte pattern 00 00 ff ff of a sync-flush marker (deflate.c:1064-1076) -- the block
+//        behind it starts on the next byte, whatever its type.
+//   F2 validate_headers_kernel  one lane per survivor decodes the whole header (inflate.c:814-917) and applies the
+//        validity rules of inflate_table to the two code sets (inftrees.c:104-137): about 1 random position in 10^6
+//        survives both kernels, real block starts all do.
+//   host                        sorts the few thousand candidates (at least 2 KiB of compressed bytes apart); bit 0 is
+//        always a start.
+//   P  inflate_streams_kernel<PART>  one wavefront per part, from its start until a block ends EXACTLY on a later start
+//        (or BFINAL), 16-bit symbols into the part's own slot (a symbol >= 256 names a byte of the 32 KiB in front of
+//        the part: nobody knows yet what is there).
+//   host                        chains the parts from bit 0: part 0 is genuine, the part that starts where it ended is
+//        therefore genuine too, ...; a candidate that was noise is simply never reached (and the part in front of it has
+//        run across it).  Then every part's place in the output is known.
+//   C  compact_parts_kernel     slots -> one symbol array, consecutive parts grouped into segments of >= 40 KiB (the
+//        context chain of inflate_resolve.hip looks one segment back) with their references re-based to the segment;
+//        K2 / K3 of inflate_resolve.hip resolve and translate.
+// Anything irregular on the chain -- a data error, a truncated stream, a distance too far back, no candidates (a stream of fixed-Huffman blocks only) -- sends the call to the sequential host decoder, which
+// then reports exactly what the reference would (status, message, bytes produced, bytes consumed).
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "context.h"
+#include "deflate_dev.h"
+#include "inflate_dev.h"
+
+namespace zr {
+
+constexpr uint32_t kSpacingBytes = 2u << 10;      // least compressed bytes between two starts
+constexpr uint32_t kSegmentBytes = 40u << 10;     // parts are grouped into segments of at least this much OUTPUT for the
+                                                  // context chain (which looks one segment back: >= 32 KiB each)
+constexpr uint32_t kSlotRatio = 64;               // symbols of slot per compressed byte of the part ...
+constexpr uint32_t kSlotSlack = 640u << 10;       // ... plus this (a 512 KiB run of one byte is ~600 bytes of deflate data)
+
+// 64 bits of the stream starting at `bit` (bits beyond the end read 0)
+__device__ __forceinline__ unsigned long long bits_at_dev(const uint8_t *src, unsigned long long src_len, unsigned long long bit) {
+    const unsigned long long byte = bit >> 3;
+    unsigned long long lo = 0, hi = 0;
+    if (byte + 16 <= src_len) {
+        const u32x4_unaligned v = load_u128(src + byte);
+        lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+        hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    } else {
+        for (unsigned k = 0; k < 16 && byte + k < src_len; ++k) {
+            const unsigned long long b = load_u8(src + byte + k);
+            if (k < 8) lo |= b << (8 * k);
+            else hi |= b << (8 * (k - 8));
+        }
+    }
+    const unsigned s = (unsigned)(bit & 7ull);
+    return s ? (lo >> s) | (hi << (64 - s)) : lo;
+}
+
+// F1.  One lane per byte, its eight bit positions in turn; a workgroup scans a contiguous piece of the stream and collects its
+// survivors in LDS, so the global list takes one atomic per workgroup and flush (a single contended word manages ~90
+// atomics per microsecond: one per survivor would cost more than the scan).  cand: bit position, bit 63 set for "block
+// behind a marker".
+constexpr uint32_t kFindLocal = 2048;
+__global__ __launch_bounds__(256)
+void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src_len, unsigned long long *__restrict__ cand,
+                         uint32_t *__restrict__ ncand, uint32_t cap) {
+    __shared__ uint8_t kraft9[512];             // three 3-bit code lengths -> their share of the Kraft sum, in 1/128
+    __shared__ unsigned long long local[kFindLocal];
+    __shared__ uint32_t nlocal, gbase;
+    for (int v = threadIdx.x; v < 512; v += 256) {
+        unsigned sum = 0;
+        for (int f = 0; f < 3; ++f) {
+            const unsigned l = (v >> (3 * f)) & 7;
+            if (l) sum += 128u >> l;
+        }
+        kraft9[v] = (uint8_t)sum;
+    }
+    if (threadIdx.x == 0) nlocal = 0;
+    __syncthreads();
+    auto flush = [&]() {                         // all threads
+        __syncthreads();
+        const uint32_t n = nlocal < kFindLocal ? nlocal : kFindLocal;
+        if (threadIdx.x == 0) gbase = n ? atomicAdd(ncand, n) : 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            if (gbase + i < cap) cand[gbase + i] = local[i];
+        __syncthreads();
+        if (threadIdx.x == 0) nlocal = 0;
+        __syncthreads();
+    };
+    const unsigned long long per = (src_len + gridDim.x - 1) / gridDim.x;
+    const unsigned long long lo_b = per * blockIdx.x, hi_b = lo_b + per < src_len ? lo_b + per : src_len;
+    for (unsigned long long base = lo_b; base < hi_b; base += 256) {
+        const unsigned long long b = base + threadIdx.x;
+        if (b < hi_b && b + 8 < src_len) {
+            unsigned long long lo = 0, hi = 0;
+            if (b + 16 <= src_len) {
+                const u32x4_unaligned v = load_u128(src + b);
+                lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+                hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+            } else {
+                for (unsigned k = 0; k < 16 && b + k < src_len; ++k) {
+                    const unsigned long long x = load_u8(src + b + k);
+                    if (k < 8) lo |= x << (8 * k);
+                    else hi |= x << (8 * (k - 8));
+                }
+            }
+            if ((uint32_t)lo == 0xffff0000u && b + 6 <= src_len) {       // 00 00 ff ff: the block behind the marker
+                const uint32_t i = atomicAdd(&nlocal, 1u);
+                if (i < kFindLocal) local[i] = (8ull * (b + 4)) | (1ull << 63);
+            }
+#pragma unroll
+            for (unsigned k = 0; k < 8; ++k) {
+                const unsigned long long v = k ? (lo >> k) | (hi << (64 - k)) : lo;
+                const uint32_t h = (uint32_t)v & 8191u;
+                if (((h >> 1) & 3u) != 2u || ((h >> 3) & 31u) > 29u || ((h >> 8) & 31u) > 29u) continue;
+                const unsigned ncode = ((uint32_t)(v >> 13) & 15u) + 4u;
+                unsigned long long c = (lo >> (k + 17)) | (hi << (64 - (k + 17)));       // 57 bits: all 19 fields
+                if (ncode < 19) c &= (1ull << (3 * ncode)) - 1ull;
+                unsigned sum = 0;
+#pragma unroll
+                for (int g = 0; g < 7; ++g) sum += kraft9[(uint32_t)(c >> (9 * g)) & 511u];
+                if (sum != 128u) continue;
+                const uint32_t i = atomicAdd(&nlocal, 1u);
+                if (i < kFindLocal) local[i] = 8ull * b + k;
+            }
+        }
+        // 2048 positions per round leave ~2 survivors on real data; a round of adversarial data could fill the list
+        __syncthreads();
+        const uint32_t nl = nlocal;                     // the same value for every thread: nobody adds between the barriers
+        __syncthreads();
+        if (nl > kFindLocal / 4) flush();
+    }
+    flush();
+}
+
+// F2.  One lane per survivor of F1: the whole dynamic header (inflate.c:814-917) and inflate_table's validity rules for the
+// literal/length and the distance code (inftrees.c:104-137).  Per lane in LDS: the code-length code as a 128-entry direct
+// table (length << 5 | symbol) and the 316 code lengths.  valid[i] = 1 / 0.
+constexpr int kValLanes = 64;
+__global__ __launch_bounds__(kValLanes)
+void validate_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src_len,
+                             const unsigned long long *__restrict__ cand, uint32_t n, uint8_t *__restrict__ valid) {
+    __shared__ uint8_t tab[kValLanes][128];
+    __shared__ uint8_t lens[kValLanes][320];
+    const uint32_t i = blockIdx.x * kValLanes + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c0 = cand[i];
+    if (c0 >> 63) {                                       // behind a marker: taken as it is
+        valid[i] = 1;
+        return;
+    }
+    valid[i] = 0;
+    uint8_t *T = tab[threadIdx.x], *Ln = lens[threadIdx.x];
+    const unsigned long long bit = c0;
+    unsigned long long w = bits_at_dev(src, src_len, bit + 3);
+    const unsigned nlen = (unsigned)(w & 31) + 257, ndist = (unsigned)((w >> 5) & 31) + 1, ncode = (unsigned)((w >> 10) & 15) + 4;
+    if (nlen > 286 || ndist > 30) return;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19];
+#pragma unroll
+    for (int k = 0; k < 19; ++k) cl[k] = 0;
+    unsigned long long pos = bit + 17;
+    {
+        const unsigned long long f = bits_at_dev(src, src_len, pos);
+        for (unsigned k = 0; k < ncode; ++k) {
+            const unsigned l = (unsigned)(f >> (3 * k)) & 7u;
+            // cl[order[k]] = l without a dynamically indexed register array
+#pragma unroll
+            for (int s = 0; s < 19; ++s)
+                if (order[k] == s) cl[s] = (uint8_t)l;
+        }
+        pos += 3ull * ncode;
+    }
+    if ((pos >> 3) + 8 > src_len) return;
+    // canonical code of the code-length code -> direct table (complete: F1 checked the Kraft sum)
+    unsigned count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 19; ++s) {
+#pragma unroll
+        for (int l = 1; l < 8; ++l)
+            if (cl[s] == l) ++count[l];
+    }
+    unsigned next[8];
+    {
+        unsigned code = 0;
+#pragma unroll
+        for (int l = 1; l < 8; ++l) {
+            code = (code + count[l - 1]) << 1;
+            next[l] = code;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 19; ++s) {
+        const unsigned l = cl[s];
+        if (!l) continue;
+        unsigned code = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            if (l == (unsigned)q) code = next[q]++;
+        const unsigned rev = __builtin_bitreverse32(code) >> (32 - l);
+        for (unsigned e = rev; e < 128; e += 1u << l) T[e] = (uint8_t)((l << 5) | (unsigned)s);
+    }
+    unsigned have = 0;
+    const unsigned total = nlen + ndist;
+    while (have < total) {
+        const unsigned long long v = bits_at_dev(src, src_len, pos);
+        const unsigned e = T[(unsigned)v & 127u];
+        const unsigned nb = e >> 5, sym = e & 31u;
+        pos += nb;
+        if (sym < 16) {
+            Ln[have++] = (uint8_t)sym;
+            continue;
+        }
+        unsigned rep, val = 0;
+        const unsigned long long x = v >> nb;
+        if (sym == 16) {
+            if (have == 0) return;
+            val = Ln[have - 1];
+            rep = 3 + (unsigned)(x & 3);
+            pos += 2;
+        } else if (sym == 17) {
+            rep = 3 + (unsigned)(x & 7);
+            pos += 3;
+        } else {
+            rep = 11 + (unsigned)(x & 127);
+            pos += 7;
+        }
+        if (have + rep > total) return;
+        while (rep--) Ln[have++] = (uint8_t)val;
+        if ((pos >> 3) + 8 > src_len) return;
+    }
+    if (Ln[256] == 0) return;                             // no end-of-block code (inflate.c:897-901)
+    // inflate_table's checks on both sets: not over-subscribed; incomplete only with a single code of length 1
+    for (int set = 0; set < 2; ++set) {
+        const unsigned from = set ? nlen : 0, cnt = set ? ndist : nlen;
+        unsigned c16[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) c16[l] = 0;
+        for (unsigned s = 0; s < cnt; ++s) {
+            const unsigned l = Ln[from + s];
+#pragma unroll
+            for (int q = 1; q < 16; ++q)
+                if (l == (unsigned)q) ++c16[q];
+        }
+        int left = 1, max = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) {
+            left = (left << 1) - (int)c16[l];
+            if (left < 0) return;
+            if (c16[l]) max = l;
+        }
+        if (max == 0) {
+            if (set == 0) return;                         // no literal/length code at all
+            continue;                                     // no distance codes: allowed (inftrees.c:114-122)
+        }
+        if (left > 0 && max != 1) return;
+    }
+    valid[i] = 1;
+}
+
+struct PartCopy {
+    const uint16_t *src;      // the part's slot
+    uint64_t        dst;      // its first symbol's index in the stream's symbol array
+    uint64_t        gstart;   // first symbol of the SEGMENT (group of consecutive parts) it belongs to
+    uint32_t        n;
+    uint32_t        first;    // chain index of the segment's first part
+};
+
+// C.  grid.y = part on the chain: its symbols go to their place in the stream's symbol array.  A part's references count
+// back from the PART's first byte; the context chain wants them counted from the SEGMENT's: a reference that lands inside
+// an earlier part of the same segment is replaced by the symbol that part has there (itself possibly a reference: the
+// loop follows it), one that lands in front of the segment is re-based.
+__global__ __launch_bounds__(256)
+void compact_parts_kernel(const PartCopy *__restrict__ parts, uint16_t *__restrict__ sym) {
+    const uint32_t j0 = blockIdx.y;
+    const PartCopy p = parts[j0];
+    uint16_t *d = sym + p.dst;
+    const bool rebase = p.dst != p.gstart;               // a segment's first part needs nothing
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    auto fix = [&](uint32_t v) -> uint32_t {             // a reference of this part, counted from the segment's first byte
+        uint32_t j = j0;
+        uint64_t base = p.dst;                           // first symbol of the part v counts back from
+        for (;;) {
+            const uint64_t k = 33024u - v;               // bytes in front of `base`, 1 .. 32768
+            if (base - p.gstart < k) return 33024u - (uint32_t)(k - (base - p.gstart));      // in front of the segment
+            const uint64_t g = base - k;                 // a symbol of an earlier part of this segment
+            do --j; while (parts[j].dst > g);
+            v = parts[j].src[g - parts[j].dst];
+            if (v < 256u) return v;
+            base = parts[j].dst;
+        }
+    };
+    // 8 symbols (16 bytes) per lane where the destination allows it (slots are 16-byte aligned)
+    const uint32_t lead = (uint32_t)((8u - (((uintptr_t)d >> 1) & 7u)) & 7u);
+    for (uint32_t q = gid; q < lead && q < p.n; q += gsz) {
+        uint32_t v = p.src[q];
+        if (rebase && v >= 256u) v = fix(v);
+        d[q] = (uint16_t)v;
+    }
+    if (p.n > lead) {
+        const uint32_t chunks = (p.n - lead) >> 3;
+        for (uint32_t c = gid; c < chunks; c += gsz) {
+            const uint32_t at = lead + 8u * c;
+            uint16_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p.src[at + k];
+            if (rebase) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (v[k] >= 256u) v[k] = (uint16_t)fix(v[k]);
+            }
+            *reinterpret_cast<uint4 *>(d + at) = *reinterpret_cast<const uint4 *>(v);
+        }
+        for (uint32_t q = lead + 8u * chunks + gid; q < p.n; q += gsz) {
+            uint32_t v = p.src[q];
+            if (rebase && v >= 256u) v = fix(v);
+            d[q] = (uint16_t)v;
+        }
+    }
+}
+
+// inflate_resolve.hip: symbols -> bytes (window in front, context chain, translate)
+int inflate_resolve_symbols(const uint64_t *d_segs, size_t nsegs, uint16_t *sym, uint8_t *d_out, const uint8_t *d_window,
+                            uint32_t window_len, hipStream_t st);
+
+static thread_local int t_large_parts = 0;
+
+// why the device path handed the stream to the sequential decoder (readable through zng_rocm_last_error())
+static int why(const char *reason) {
+    set_error("inflate_large: sequential decoder (%s)", reason);
+    return 0;
+}
+
+// returns 1 with *out_len / *in_used set, or 0 = "irregular: use the sequential decoder", or a negative error
+static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                             uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st) {
+    if (src_len < (128u << 10) || src_len >= (1ull << 31)) return why("stream below 128 KiB (or 2 GiB and more)");
+    // ---- candidates ---------------------------------------------------------------------------------------------
+    const uint32_t cap1 = (uint32_t)std::min<size_t>(src_len / 64 + 4096, 64u << 20);
+    uint8_t *fp = nullptr;
+    if (int rc = scratch_reserve(ws, kScrLargeCand, (size_t)cap1 * 9 + 64, false, (void **)&fp)) return rc;
+    unsigned long long *d_cand = (unsigned long long *)fp;
+    uint8_t *d_valid = fp + (size_t)cap1 * 8;
+    uint32_t *d_n = (uint32_t *)(d_valid + (((size_t)cap1 + 15) & ~(size_t)15));
+    ZR_HIP(hipMemsetAsync(d_n, 0, 4, st));
+    hipLaunchKernelGGL(find_headers_kernel, dim3(4096), dim3(256), 0, st, d_src, (unsigned long long)src_len, d_cand, d_n, cap1);
+    ZR_HIP(hipGetLastError());
+    uint32_t n1 = 0;
+    ZR_HIP(hipMemcpyAsync(&n1, d_n, 4, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipStreamSynchronize(st));
+    if (n1 == 0 || n1 > cap1) return why("no candidate block starts, or far more than a deflate stream has");
+    hipLaunchKernelGGL(validate_headers_kernel, dim3((n1 + kValLanes - 1) / kValLanes), dim3(kValLanes), 0, st, d_src,
+                       (unsigned long long)src_len, d_cand, n1, d_valid);
+    ZR_HIP(hipGetLastError());
+    std::vector<unsigned long long> cand(n1);
+    std::vector<uint8_t> valid(n1);
+    ZR_HIP(hipMemcpyAsync(cand.data(), d_cand, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipMemcpyAsync(valid.data(), d_valid, n1, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> good;
+    good.reserve(n1);
+    for (uint32_t i = 0; i < n1; ++i)
+        if (valid[i]) good.push_back(cand[i] & ~(1ull << 63));
+    std::sort(good.begin(), good.end());
+    std::vector<unsigned long long> starts;
+    starts.push_back(0);
+    for (unsigned long long b : good)
+        if (b >= starts.back() + 8ull * kSpacingBytes && (b >> 3) + 16 < src_len) starts.push_back(b);
+    const size_t np = starts.size();
+    if (np < 4) return why("fewer than four block starts found");
+
+    // ---- parts ----------------------------------------------------------------------------------------------------
+    std::vector<uint64_t> slot_off(np + 1, 0);
+    const uint64_t slack = std::max<uint64_t>(64u << 10, std::min<uint64_t>(kSlotSlack, (2ull << 30) / np));
+    for (size_t i = 0; i < np; ++i) {
+        const uint64_t bytes = ((i + 1 < np ? starts[i + 1] : 8ull * src_len) - starts[i] + 7) >> 3;
+        uint64_t capi = bytes * kSlotRatio + slack;
+        capi = (capi + 7) & ~7ull;
+        slot_off[i + 1] = slot_off[i] + capi;
+    }
+    uint8_t *sp = nullptr;
+    const size_t jobs_b = (np * sizeof(InflateJobDev) + 255) & ~(size_t)255, starts_b = (np * 8 + 255) & ~(size_t)255,
+                 res_b = (np * 32 + 255) & ~(size_t)255, slots_b = slot_off[np] * 2;
+    if (scratch_reserve(ws, kScrLargeParts, jobs_b + starts_b + res_b + slots_b, false, (void **)&sp) != ZNG_ROCM_OK)
+        return why("no room for the part slots");
+    InflateJobDev *d_jobs = (InflateJobDev *)sp;
+    unsigned long long *d_starts = (unsigned long long *)(sp + jobs_b);
+    uint32_t *d_res = (uint32_t *)(sp + jobs_b + starts_b);
+    uint16_t *d_slots = (uint16_t *)(sp + jobs_b + starts_b + res_b);
+    std::vector<InflateJobDev> jobs(np);
+    for (size_t i = 0; i < np; ++i)
+        jobs[i] = InflateJobDev{d_src, (uint8_t *)(d_slots + slot_off[i]), src_len, slot_off[i + 1] - slot_off[i],
+                                i == 0 ? window_len : 32768u, 0u};
+    ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
+    ZR_HIP(hipMemcpyAsync(d_starts, starts.data(), np * 8, hipMemcpyHostToDevice, st));
+    if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, st)) return rc;
+    std::vector<uint32_t> res(np * 8);
+    ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipStreamSynchronize(st));
+    // parts whose slot was too small (more than kSlotRatio : 1): once more, with room for deflate's worst case (1032 : 1)
+    uint8_t *bigp = nullptr;
+    std::vector<uint16_t *> slot_ptr(np);
+    for (size_t i = 0; i < np; ++i) slot_ptr[i] = d_slots + slot_off[i];
+    {
+        std::vector<size_t> again;
+        uint64_t need = 0;
+        for (size_t i = 0; i < np; ++i)
+            if (res[8 * i + 4] == kMsgOutFull) {
+                again.push_back(i);
+                const uint64_t bytes = ((i + 1 < np ? starts[i + 1] : 8ull * src_len) - starts[i] + 7) >> 3;
+                need += (bytes * 1032u + kSlotSlack + 7) & ~7ull;
+            }
+        if (!again.empty()) {
+            if (need * 2 > (24ull << 30) || scratch_reserve(ws, kScrLargeRetry, need * 2, false, (void **)&bigp) != ZNG_ROCM_OK)
+                return why("parts with a ratio above 64 need more scratch than is reasonable");
+            for (size_t i = 0; i < np; ++i) jobs[i].out_cap = 0;
+            uint64_t at = 0;
+            for (size_t i : again) {
+                const uint64_t bytes = ((i + 1 < np ? starts[i + 1] : 8ull * src_len) - starts[i] + 7) >> 3;
+                const uint64_t capi = (bytes * 1032u + kSlotSlack + 7) & ~7ull;
+                slot_ptr[i] = (uint16_t *)bigp + at;
+                jobs[i].out = (uint8_t *)slot_ptr[i];
+                jobs[i].out_cap = capi;
+                at += capi;
+            }
+            ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
+            if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, st)) return rc;
+            ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
+            ZR_HIP(hipStreamSynchronize(st));
+        }
+    }
+
+    // ---- the chain from bit 0 -------------------------------------------------------------------------------------
+    std::vector<PartCopy> copies;
+    uint64_t produced = 0;
+    size_t cur = 0;
+    unsigned long long end_bit = 0;
+    for (;;) {
+        const uint32_t *r = &res[8 * cur];
+        const bool ended = r[3] == 1u;
+        if (r[4] != kMsgNone || !(ended || r[6] != 0xffffffffu)) {                // error / truncation on the chain
+            set_error("inflate_large: sequential decoder (part %zu of %zu at bit %llu: message %u \"%s\", %u symbols of %llu, "
+                      "ended on %d)", cur, np, starts[cur], r[4], zng_rocm_inflate_message(r[4]), r[0],
+                      (unsigned long long)jobs[cur].out_cap, (int)r[6]);
+            return 0;
+        }
+        if ((uint64_t)r[5] > produced + window_len) return why("a distance reaches in front of the stream");
+        copies.push_back(PartCopy{slot_ptr[cur], produced, 0, r[0], 0u});
+        produced += r[0];
+        end_bit = (unsigned long long)r[1] | ((unsigned long long)r[2] << 32);
+        if (ended) break;
+        cur = r[6];
+        if (cur >= np) return why("bad chain link");
+    }
+    // segments for the context chain: consecutive parts until kSegmentBytes of output are together; what is left at the end
+    // joins the last segment unless it is a segment's worth itself (only the stream's LAST segment may be short)
+    std::vector<uint64_t> segs;                           // triples as inflate_resolve.hip wants them; only [3 s + 1] is used
+    {
+        size_t first = 0;
+        std::vector<size_t> seg_first;
+        for (size_t c = 0; c < copies.size(); ++c) {
+            if (copies[c].dst + copies[c].n - copies[first].dst >= kSegmentBytes || c + 1 == copies.size()) {
+                seg_first.push_back(first);
+                first = c + 1;
+            }
+        }
+        if (seg_first.size() > 1 && produced - copies[seg_first.back()].dst < 32768u) seg_first.pop_back();
+        seg_first.push_back(copies.size());
+        for (size_t g = 0; g + 1 < seg_first.size(); ++g) {
+            for (size_t c = seg_first[g]; c < seg_first[g + 1]; ++c) {
+                copies[c].gstart = copies[seg_first[g]].dst;
+                copies[c].first = (uint32_t)seg_first[g];
+            }
+            segs.push_back(0);
+            segs.push_back(copies[seg_first[g]].dst);
+            segs.push_back(0);
+        }
+    }
+    segs.push_back(0);
+    segs.push_back(produced);
+    segs.push_back(0);
+    if (out_len) *out_len = produced;
+    if (in_used) *in_used = (size_t)((end_bit + 7) >> 3);
+    if (produced > dst_cap) {
+        set_error("inflate output (%llu bytes) exceeds dst_cap", (unsigned long long)produced);
+        return -5;
+    }
+    const size_t nparts = copies.size();
+    const size_t nsegs = segs.size() / 3 - 1;
+    // ---- symbols in place, resolve, translate ---------------------------------------------------------------------
+    uint8_t *yp = nullptr;
+    const size_t sym_b = ((size_t)produced + 32768 + 64) * 2, segs_b = (segs.size() * 8 + 255) & ~(size_t)255,
+                 cp_b = (nparts * sizeof(PartCopy) + 255) & ~(size_t)255;
+    if (scratch_reserve(ws, kScrLargeSym, segs_b + cp_b + sym_b, false, (void **)&yp) != ZNG_ROCM_OK) return why("no room for the symbols");
+    uint64_t *d_segs = (uint64_t *)yp;
+    PartCopy *d_cp = (PartCopy *)(yp + segs_b);
+    uint16_t *sym = (uint16_t *)(yp + segs_b + cp_b) + 32768;
+    ZR_HIP(hipMemcpyAsync(d_segs, segs.data(), segs.size() * 8, hipMemcpyHostToDevice, st));
+    ZR_HIP(hipMemcpyAsync(d_cp, copies.data(), nparts * sizeof(PartCopy), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(compact_parts_kernel, dim3(16, (unsigned)nparts), dim3(256), 0, st, d_cp, sym);
+    ZR_HIP(hipGetLastError());
+    if (int rc = inflate_resolve_symbols(d_segs, nsegs, sym, d_dst, d_window, window_len, st)) return rc;
+    ZR_HIP(hipStreamSynchronize(st));
+    t_large_parts = (int)nparts;
+    return 1;
+}
+
+}  // namespace zr
+
+using namespace zr;
+
+extern "C" {
+
+int zng_rocm_inflate_large_last_parts(void) { return t_large_parts; }
+
+int zng_rocm_inflate_large_dev(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
+                               uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if ((!d_src && src_len) || window_len > 32768u || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
+    DeviceGuard dev;
+    hipStream_t st = (hipStream_t)stream;
+    t_large_parts = 0;
+    {
+        Workspace *ws = workspace_for(st);               // scratch is keyed by the caller's HIP stream (context.h)
+        if (!ws) return ZNG_ROCM_ENOMEM;
+        std::lock_guard<std::mutex> use(ws->mu);
+        const int rc = inflate_large_try(ws, d_src, src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, st);
+        if (rc != 0) return rc;
+    }
+    // irregular: the sequential decoder on a host copy of the stream says exactly what the reference would
+    std::vector<uint8_t> host(src_len ? src_len : 1);
+    if (src_len) {
+        ZR_HIP(hipMemcpyAsync(host.data(), d_src, src_len, hipMemcpyDeviceToHost, st));
+        ZR_HIP(hipStreamSynchronize(st));
+    }
+    return zng_rocm_inflate_raw_window(host.data(), src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, stream);
+}
+
+}  // extern "C"

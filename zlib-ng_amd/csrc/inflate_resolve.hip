@@ -268,6 +268,27 @@ int inflate_resolve_batch(const uint32_t *d_tokens, const uint8_t *d_literals, s
     return ZNG_ROCM_OK;
 }
 
+// symbols that are already in place (inflate_large.hip) -> bytes: the window in front, the context chain, the translation
+int inflate_resolve_symbols(const uint64_t *d_segs, size_t nsegs, uint16_t *sym, uint8_t *d_out, const uint8_t *d_window,
+                            uint32_t window_len, hipStream_t st) {
+    if (!nsegs) return ZNG_ROCM_OK;
+    hipLaunchKernelGGL(inflate_window_kernel, dim3((unsigned)(kCtx / 256)), dim3(256), 0, st, d_window, window_len, sym);
+    ZR_HIP(hipGetLastError());
+    if (nsegs > 1) {
+        const unsigned ngroups = (unsigned)((nsegs - 1 + kGroup - 1) / kGroup);
+        hipLaunchKernelGGL(inflate_context_group_kernel, dim3(ngroups), dim3(1024), 0, st, d_segs, nsegs, sym, 1);
+        ZR_HIP(hipGetLastError());
+        if (ngroups > 1) {
+            hipLaunchKernelGGL(inflate_context_chain_kernel, dim3(1), dim3(1024), 0, st, d_segs, nsegs, sym);
+            ZR_HIP(hipGetLastError());
+        }
+    }
+    ZR_LAUNCH_TRACED(inflate_translate_kernel, dim3((unsigned)nsegs), dim3(1024), st, d_segs, nsegs, sym, d_out,
+                     (const uint64_t *)nullptr, (const uint64_t *)nullptr);
+    ZR_HIP(hipGetLastError());
+    return ZNG_ROCM_OK;
+}
+
 }  // namespace zr
 
 using namespace zr;

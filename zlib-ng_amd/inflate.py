@@ -212,3 +212,18 @@ class InflateDevBatch:
         """[(status, out_len, in_used, message)] (synchronises)"""
         r = self.results.cpu().tolist()
         return [(row[2], row[0], row[1], inflate_message(row[3])) for row in r]
+
+
+def inflate_large_dev(src_dev, dst, window=None, stream=None):
+    """zng_rocm_inflate_large_dev: ONE large raw stream that is already in device memory (`src_dev`: uint8 CUDA tensor),
+    cut into parts and decoded on the device; plaintext into the CUDA tensor `dst`, optional history `window` (CUDA tensor,
+    <= 32768 bytes).  Returns (zlib status, bytes produced, compressed bytes used, parts on the chain -- 0 when the
+    sequential decoder did it)."""
+    rocm._need_init()
+    lib = rocm.lib()
+    out_len, in_used = C.c_uint64(0), C.c_size_t(0)
+    wl = 0 if window is None else int(window.numel())
+    st = lib.zng_rocm_inflate_large_dev(rocm._dev_ptr(src_dev), int(src_dev.numel()),
+                                        rocm._dev_ptr(window) if wl else None, wl, rocm._dev_ptr(dst), int(dst.numel()),
+                                        C.byref(out_len), C.byref(in_used), rocm._stream_ptr(stream))
+    return st, int(out_len.value), int(in_used.value), int(lib.zng_rocm_inflate_large_last_parts())
