@@ -66,7 +66,46 @@ def host_threads():
     return n
 
 
-def cpu_baseline(host_view, zr, reps=3):
+def system_zlib_probe(ptr, n, reps):
+    """when the box has a system libz-ng.so.2 / libz.so.1, time ITS adler32 / crc32 on the same bytes
+    (one thread), labelled by zlibVersion() -- whatever it is, it is not this repository's code.  None when neither loads."""
+    import ctypes as C
+    for name, pre in (("libz-ng.so.2", "zng_"), ("libz.so.1", "")):
+        try:
+            lib = C.CDLL(name)
+            ver = getattr(lib, ("zlibng_version" if pre else "zlibVersion"))
+            ver.restype = C.c_char_p
+            ad, cr = getattr(lib, pre + "adler32_z", None) or getattr(lib, pre + "adler32"), \
+                getattr(lib, pre + "crc32_z", None) or getattr(lib, pre + "crc32")
+        except (OSError, AttributeError):
+            continue
+        for f in (ad, cr):
+            f.restype = C.c_ulong
+            f.argtypes = [C.c_ulong, C.c_void_p, C.c_size_t]
+        chunk = 1 << 30 if ad.__name__.endswith("_z") else (1 << 31) - 1
+        ta, tc = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            a, off = 1, 0
+            while off < n:
+                ln = min(chunk, n - off)
+                a = ad(a, ptr + off, ln)
+                off += ln
+            t1 = time.perf_counter()
+            c, off = 0, 0
+            while off < n:
+                ln = min(chunk, n - off)
+                c = cr(c, ptr + off, ln)
+                off += ln
+            t2 = time.perf_counter()
+            ta.append(t1 - t0)
+            tc.append(t2 - t1)
+        return {"library": name, "version": (ver() or b"?").decode(), "cores": 1, "adler32_GBps": round(n / 1e9 / statistics.median(ta), 3),
+                "crc32_GBps": round(n / 1e9 / statistics.median(tc), 3), "checks": [a & 0xffffffff, c & 0xffffffff]}
+    return None
+
+
+def cpu_baseline(host_view, zr, reps=5):
     """The CPU checker timed on this box's host cores over the step's own bytes: adler32 = the oracle port of
     adler32_c.c, crc32 = the reference's crc32_braid_c.c (oracle/_ref) when it was built.  Two figures (BASELINE.md
     section 3): one thread, and T threads each on its own contiguous slice folded with the combine operators."""
@@ -92,7 +131,17 @@ def cpu_baseline(host_view, zr, reps=3):
     cuts = [n * k // T for k in range(T + 1)]
     part = [None] * T
 
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = []
+
     def work(k):
+        if cpus:                                             # one thread per core, pinned
+            try:
+                os.sched_setaffinity(0, {cpus[k % len(cpus)]})
+            except OSError:
+                pass
         p, ln = ptr + cuts[k], cuts[k + 1] - cuts[k]
         part[k] = (orc.oracle_adler32(1, p, ln), crc_fn(0, p, ln), ln)
 
@@ -112,6 +161,9 @@ def cpu_baseline(host_view, zr, reps=3):
         multi.append(time.perf_counter() - t0)
     assert (am, cm) == (a, c), "T-thread slices + combine differ from the one-thread value"
     crc_name = "reference crc32_braid_c.c via oracle/_ref" if ref_crc is not None else "oracle port of crc32_braid_c.c"
+    system = system_zlib_probe(ptr, n, reps)
+    if system is not None:
+        assert system.pop("checks") == [a, c], "the system zlib disagrees with the checker"
     return {
         "value": round(gb / statistics.median(pair), 3),
         "unit": "GB/s",
@@ -123,7 +175,8 @@ def cpu_baseline(host_view, zr, reps=3):
         "crc32_GBps": round(gb / statistics.median(tc), 3),
         "multi": {"value": round(gb / statistics.median(multi), 3), "unit": "GB/s", "cores": T,
                   "sample": "same buffer cut into %d contiguous slices, one thread each (all host cores this process "
-                            "may use), adler32 then crc32 per slice, folded with adler32_combine / crc32_combine" % T},
+                            "may use, pinned), adler32 then crc32 per slice, folded with adler32_combine / crc32_combine; median of %d" % (T, reps)},
+        "system_zlib": system,
         "reference_container": REFERENCE_CONTAINER,
     }, (a, c)
 
@@ -414,7 +467,18 @@ def run_single_stream_legs(args, zr, torch, dist, dev, world, rank):
     assert res["rc"][:2] == (1, n) and torch.equal(out[:n], src), "inflate output differs from the plaintext"
     parts = zr.lib().zng_rocm_inflate_threads_last_parts()
     t_inf1 = timed(lambda: inf.inflate_raw_threads(hs, out, nthreads=1), 1)
-    del src, dst, out
+    # the same stream, already in device memory, decoded on the device alone (zng_rocm_inflate_large_dev): block starts found
+    # by a device kernel, one wavefront per part, the host only sorts candidates and walks the chain
+    d_comp = dst[:clen].contiguous()
+    out.zero_()
+    inf.inflate_large_dev(d_comp, out)
+    big = {}
+
+    def run_large():
+        big["rc"] = inf.inflate_large_dev(d_comp, out)
+    t_large = timed(run_large, 3)
+    assert big["rc"][:3] == (1, n, clen) and torch.equal(out[:n], src), "device inflate output differs from the plaintext"
+    del src, dst, out, d_comp
     torch.cuda.empty_cache()
     if rank != 0:
         return None
@@ -429,6 +493,10 @@ def run_single_stream_legs(args, zr, torch, dist, dev, world, rank):
                     "value": round(world * gb / t_inf, 2), "unit": "GB/s of output", "ms_per_stream": round(t_inf * 1e3, 2),
                     "in_GBps": round(world * clen / 1e9 / t_inf, 2), "host_threads": T, "parts_joined": parts,
                     "one_host_thread_GBps": round(gb / t_inf1, 2),
+                    "device_only": {"what": "zng_rocm_inflate_large_dev: the stream already in HBM, block starts found on the device, one "
+                                            "wavefront per part, symbols resolved by the context chain; host: sort + chain walk on 1 thread",
+                                    "GBps_of_output": round(world * gb / t_large, 2), "ms_per_stream": round(t_large * 1e3, 2),
+                                    "parts": big["rc"][3], "host_threads": 1},
                     "scaling": "replicas only" if world > 1 else "single",
                     "reference_container_GBps": REFERENCE_CONTAINER["inflate_out_GBps"]},
     }
@@ -492,8 +560,9 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if args.launch_only:
-        print(json.dumps({"launch_only": True, "rank": rank, "world": world, "local_rank": local_rank,
-                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        # one write per rank: lines of different ranks must not interleave on the shared stdout
+        os.write(1, (json.dumps({"launch_only": True, "rank": rank, "world": world, "local_rank": local_rank,
+                                 "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}) + "\n").encode())
         return
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)

@@ -269,6 +269,11 @@ int    zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs,
 size_t zng_rocm_deflate_bound(size_t source_len);
 int    zng_rocm_deflate_dev(int level, const uint8_t *d_in, size_t in_len, uint8_t *d_out, size_t out_cap,
                             size_t *out_len, void *stream);
+/* as zng_rocm_deflate_block_dev for levels 1..9, without any synchronisation: every step (matcher, block emitter, the scan that
+ * places the segments, the packing) is enqueued on `stream`; d_result (device, 2 x uint64) = {compressed size, 1 if it
+ * did not fit out_cap} once the stream has got there */
+int    zng_rocm_deflate_async_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags,
+                                  uint8_t *d_out, size_t out_cap, uint64_t *d_result, void *stream);
 int    zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags,
                                   uint8_t *d_out, size_t out_cap, size_t *out_len, void *stream);
 /* Many independent streams (or independent blocks of one input) at one of the chain levels 1..9 -- the reference's

@@ -199,3 +199,27 @@ def test_many_streams_at_a_chain_level(mods):
     joined = b"".join(pb.compressed(i) for i in range(nb))
     d = zlib.decompressobj(-15)
     assert d.decompress(joined) == whole and d.eof
+
+
+def test_async_entry_point_enqueues_without_synchronising():
+    """zng_rocm_deflate_async_dev: the whole level-6 pipeline enqueued on a caller's stream, the size
+    in device memory; two calls on two streams overlap, both streams' outputs restore their inputs"""
+    import importlib, zlib
+    import torch
+    zr = importlib.import_module("zlib-ng_amd")
+    dfl = importlib.import_module("zlib-ng_amd.deflate")
+    zr.init(0)
+    plains = [synth.silesia_like(24 << 20, seed=s) for s in (101, 202)]
+    srcs = [torch.from_numpy(p).cuda() for p in plains]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    dsts = [torch.empty(dfl.deflate_bound(p.size), dtype=torch.uint8, device="cuda") for p in plains]
+    ress = [torch.full((2,), -1, dtype=torch.int64, device="cuda") for _ in plains]
+    torch.cuda.synchronize()
+    for s, d, r, st in zip(srcs, dsts, ress, streams):
+        dfl.deflate_async_dev(s, d, r, level=6, stream=st)
+    for st in streams:
+        st.synchronize()
+    for p, d, r in zip(plains, dsts, ress):
+        clen, over = (int(v) for v in r.tolist())
+        assert over == 0 and 0 < clen < p.size
+        assert zlib.decompressobj(-15).decompress(d[:clen].cpu().numpy().tobytes()) == p.tobytes()

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <vector>
 
+#define ZR_CRC_VARIANTS 1      // every tuning variant of the kernel, including the two timing-only ones
 #include "checksum_kernel.h"
 #include "tables.h"
 

@@ -149,13 +149,19 @@ __device__ __forceinline__ uint32_t mul_by_rows(const uint4 *rows, int stride, i
     return acc;
 }
 
-// Tuning switches of the CRC prologue / epilogue (bit mask V).  The product instantiates kCrcVariant only; the others
-// exist so that tools/micro/crc_phases.hip can time each change by itself on the same build.
+// Tuning switches of the CRC prologue / epilogue (bit mask V).  The PRODUCT build can instantiate kCrcVariant only (a
+// static_assert in stream_body); tools/micro/crc_phases.hip defines ZR_CRC_VARIANTS and times every other setting -- the
+// kernel's history -- on the same build.  The two timing-only settings that skip work (and return a wrong CRC) do not
+// exist without that macro.
 constexpr int kVarBothBuffers = 1;    // request BOTH register buffers before the table image is built
 constexpr int kVarFoldX32     = 2;    // braid fold through x^32 tables: 3 LDS latencies instead of 12
 constexpr int kVarEarlyPow    = 4;    // fetch the lane's 32 partial products before the main loop, not after it
+#ifdef ZR_CRC_VARIANTS
 constexpr int kVarNoReplicate = 16;   // TIMING ONLY (wrong CRC): skip the 128 KiB replication
 constexpr int kVarNoMultiply  = 32;   // TIMING ONLY (wrong CRC): skip the per-lane weight multiply
+#else
+constexpr int kVarNoReplicate = 0, kVarNoMultiply = 0;       // not in the product: the tests below fold to "do the work"
+#endif
 constexpr int kVarBuildTables = 64;   // build the table entries in registers from CrcBits: no table fetch in the prologue
 constexpr int kVarLdsBarrier  = 128;  // prologue barriers wait for LDS only, not for the data loads already in flight
 constexpr int kVarByteAddr    = 1024; // table image with the index in byte 1 of the LDS address: one SDWA move per lookup
@@ -181,6 +187,9 @@ constexpr int kCrcVariant = kVarFoldX32 | kVarBuildTables | kVarLdsBarrier | kVa
 template <bool DO_ADLER, bool DO_CRC, bool COPY, int V, bool PROFILE, int UNROLL>
 __device__ __forceinline__ void stream_body(const StreamArgs &args, const DeviceTables *__restrict__ tabs,
                                             Partial *__restrict__ partials, const long long G, const long long g) {
+#ifndef ZR_CRC_VARIANTS
+    static_assert(V == kCrcVariant, "the product instantiates the one tuned variant; the others are for tools/micro/crc_phases.hip");
+#endif
     // 64 KiB alignment: with kVarByteAddr byte 1 of a lookup address must be free for the index (braid_step_bytes)
     __shared__ __attribute__((aligned(65536))) uint32_t lut[DO_CRC ? 4 * 256 * 32 : 32];
     // linear copies: the four stride tables, the byte table, the four x^32 tables

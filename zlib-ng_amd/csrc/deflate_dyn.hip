@@ -758,7 +758,8 @@ static const uint32_t kLevelCand[10] = {0, 1, 2, 3, 6, 8, 16, 16, 16, 16};
 // pinned host words {compressed size, does-not-fit flag} per stream, valid once the stream has been synchronised.
 // cap_override: out_cap of job 0 when the caller's job struct cannot hold it (a single stream of >= 4 GiB of room).
 static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, size_t njobs, const size_t *cap_override,
-                                uint32_t seg_bytes, Workspace *ws, hipStream_t st, unsigned long long **results) {
+                                uint32_t seg_bytes, Workspace *ws, hipStream_t st, unsigned long long **results,
+                                unsigned long long *d_results_copy = nullptr) {
     size_t nseg = 0;
     for (size_t s = 0; s < njobs; ++s) nseg += sjobs[s].in_len ? ((size_t)sjobs[s].in_len + seg_bytes - 1) / seg_bytes : 1;
     SegJob *d_jobs = nullptr, *jobs = nullptr;
@@ -821,7 +822,10 @@ static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, siz
     ZR_HIP(hipGetLastError());
     hipLaunchKernelGGL(gather_segments_kernel, dim3(njobs > 64 ? 4 : 16, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off);
     ZR_HIP(hipGetLastError());
-    ZR_HIP(hipMemcpyAsync(h_res, d_res, njobs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (d_results_copy)
+        ZR_HIP(hipMemcpyAsync(d_results_copy, d_res, njobs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+    else
+        ZR_HIP(hipMemcpyAsync(h_res, d_res, njobs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (int rc = host_tables_release(ws, st)) return rc;
     *results = h_res;
     return ZNG_ROCM_OK;
@@ -920,6 +924,39 @@ int zng_rocm_deflate_block_dev(int level, const uint8_t *d_in, size_t in_len, ui
     }
     *out_len = (size_t)res[0];
     return ZNG_ROCM_OK;
+}
+
+// The same with NO synchronisation: everything -- matcher, block emitter, the scan that places the segments, the packing --
+// is enqueued on `stream` and the call returns; d_result (device, 2 x u64) receives {compressed size, 1 if it did not fit
+// out_cap} when the stream gets there.  Levels 1..9.
+int zng_rocm_deflate_async_dev(int level, const uint8_t *d_in, size_t in_len, uint32_t dict_len, uint32_t flags, uint8_t *d_out,
+                               size_t out_cap, uint64_t *d_result, void *stream) {
+    if (!ctx()) {
+        set_error("zng_rocm_init() has not succeeded");
+        return ZNG_ROCM_ENODEV;
+    }
+    if (!d_result || !d_out || (!d_in && in_len) || level < 1 || level > 9 || dict_len > kPrime ||
+        (flags & ~(uint32_t)(ZNG_ROCM_BLOCK_NOT_FINAL | ZNG_ROCM_BLOCK_SYNC_FLUSH)) || in_len + dict_len >= (1ull << 32) - kSegBytes)
+        return ZNG_ROCM_EINVAL;
+    if (out_cap < zng_rocm_deflate_bound(in_len)) {
+        set_error("out_cap below zng_rocm_deflate_bound()");
+        return -5;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard dev;
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    zng_rocm_stream_job one;
+    one.in = d_in;
+    one.out = d_out;
+    one.in_len = (uint32_t)in_len;
+    one.out_cap = 0;
+    one.dict_len = dict_len;
+    one.flags = flags;
+    unsigned long long *res = nullptr;
+    return deflate_rows_enqueue(level, &one, 1, &out_cap, segment_bytes(in_len, ctx()->cus), ws, st, &res,
+                                (unsigned long long *)d_result);
 }
 
 // Many independent streams at one of the chain levels (the reference's many-stream model, test/pigz/CMakeLists.txt:123-200,

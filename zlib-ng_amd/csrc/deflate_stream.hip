@@ -549,13 +549,17 @@ int zng_rocm_deflate_quick_dev(const zng_rocm_stream_job *jobs, size_t njobs, ui
     if (int rc = host_tables_release(ws, st)) return rc;
     // Four waves per stream is the form that ships.  The one-wave-per-stream form (no barriers, 18 KiB of LDS per wave)
     // measured slower on every stream count tried (both forms are instruction-issue bound, and
-    // two waves per SIMD cover less latency than eight); ZNG_ROCM_QUICK_FORM=wave selects it for measurements.
+    // two waves per SIMD cover less latency than eight).  Measurement builds (-DZR_MEASURE_FORMS) select it with
+    // ZNG_ROCM_QUICK_FORM=wave; the product reads no environment variable.
+#ifdef ZR_MEASURE_FORMS
     static const bool wave_form = [] {                          // read once
         const char *f = getenv("ZNG_ROCM_QUICK_FORM");
         return f && f[0] == 'w';
     }();
     if (wave_form) ZR_LAUNCH_TRACED(deflate_quick_wave_kernel, dim3((unsigned)njobs), dim3(64), st, d_jobs, d_results);
-    else ZR_LAUNCH_TRACED(deflate_quick_kernel, dim3((unsigned)njobs), dim3(256), st, d_jobs, d_results);
+    else
+#endif
+    ZR_LAUNCH_TRACED(deflate_quick_kernel, dim3((unsigned)njobs), dim3(256), st, d_jobs, d_results);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }

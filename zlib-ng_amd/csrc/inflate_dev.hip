@@ -631,7 +631,9 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
 int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, hipStream_t st) {
     if (!njobs) return ZNG_ROCM_OK;
     // ring size: 4 KiB -> 16 streams per CU; 8 KiB (11 per CU) measured 25 % slower on both corpora.  The other
-    // instantiations stay for measurements (ZNG_ROCM_INFLATE_RING, read once).
+    // instantiations exist in measurement builds only (-DZR_MEASURE_FORMS, ZNG_ROCM_INFLATE_RING); the product reads no
+    // environment variable.
+#ifdef ZR_MEASURE_FORMS
     static const int ring = [] {
         const char *r = getenv("ZNG_ROCM_INFLATE_RING");
         return r ? atoi(r) : 4096;
@@ -639,7 +641,9 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
     if (ring == 8192) ZR_LAUNCH_TRACED((inflate_streams_kernel<8192, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
     else if (ring == 16384) ZR_LAUNCH_TRACED((inflate_streams_kernel<16384, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
     else if (ring == 32768) ZR_LAUNCH_TRACED((inflate_streams_kernel<32768, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
-    else ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
+    else
+#endif
+    ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, (const unsigned long long *)nullptr);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }

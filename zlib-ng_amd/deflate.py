@@ -166,3 +166,14 @@ def deflate_dev(src, level=6, length=None, offset=0, stream=None, dict_len=0, fl
                                                cap, C.byref(out_len), rocm._stream_ptr(stream))
     rocm._check(rc, "zng_rocm_deflate_block_dev")
     return dst, out_len.value
+
+
+def deflate_async_dev(src, dst, result, level=6, length=None, offset=0, stream=None, dict_len=0, flags=0):
+    """zng_rocm_deflate_async_dev: as deflate_dev, but nothing is synchronised -- `dst` (uint8 CUDA tensor of at least
+    deflate_bound(n) bytes) and `result` (int64 CUDA tensor, 2 elements: {compressed size, does-not-fit flag}) are filled
+    when `stream` gets there."""
+    rocm._need_init()
+    n = src.numel() - offset if length is None else length
+    rocm._check(rocm.lib().zng_rocm_deflate_async_dev(level, rocm._dev_ptr(src, offset), n, dict_len, flags, rocm._dev_ptr(dst),
+                                                      dst.numel(), rocm._dev_ptr(result), rocm._stream_ptr(stream)),
+                "zng_rocm_deflate_async_dev")

@@ -113,6 +113,8 @@ _PROTOS = {
                                          C.c_void_p]),
     "zng_rocm_uncompress2_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
                                            C.c_int, C.c_void_p]),
+    "zng_rocm_deflate_async_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p]),
     "zng_rocm_inflate_large_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
                                              C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.c_void_p]),
     "zng_rocm_inflate_large_last_parts": (C.c_int, []),
