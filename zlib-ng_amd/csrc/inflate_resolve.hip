@@ -222,18 +222,46 @@ void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, c
     const uint16_t *base_own = sym + ((long long)segs[3 * gs + 1] - kCtx);
     const size_t gp = s ? ((s - 1) / kGroup) * kGroup : 0;          // ... and of the previous segment's
     const uint16_t *base_prev = sym + ((long long)segs[3 * gp + 1] - kCtx);
-    for (long long i = o0 + threadIdx.x; i < stop; i += blockDim.x) {
-        uint16_t v = sym[i];
-        if (v >= 256) {
+    auto resolve = [&](uint32_t v, long long i) -> uint32_t {
+        if (v >= 256u) {
             if (i >= tail) {
-                v = base_own[v - 256];
+                v = base_own[v - 256u];
             } else {
-                v = prev[v - 256];
-                if (v >= 256) v = base_prev[v - 256];
+                v = prev[v - 256u];
+                if (v >= 256u) v = base_prev[v - 256u];
             }
         }
-        __builtin_nontemporal_store((uint8_t)v, out + i);
+        return v;
+    };
+    // eight symbols per lane and step where the symbol array allows a 16-byte load: one 8-byte store instead of eight
+    // byte stores (round 2's form moved 64 bytes per wave store; with the large-stream path's segments of 100+ KiB the
+    // kernel took 5 ms per 256 MiB)
+    const long long head = (8 - ((o0 + ((long long)((uintptr_t)sym >> 1) & 7)) & 7)) & 7;      // symbols up to 16-byte alignment of sym + i
+    const long long a0 = o0 + head < stop ? o0 + head : stop;
+    for (long long i = o0 + threadIdx.x; i < a0; i += blockDim.x)
+        __builtin_nontemporal_store((uint8_t)resolve(sym[i], i), out + i);
+    const long long chunks = (stop - a0) >> 3;
+    for (long long c = threadIdx.x; c < chunks; c += blockDim.x) {
+        const long long i = a0 + 8 * c;
+        const uint4 q = *reinterpret_cast<const uint4 *>(sym + i);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t v = resolve((w[k >> 1] >> (16 * (k & 1))) & 0xffffu, i + k);
+            if (k < 4) lo |= (v & 0xffu) << (8 * k);
+            else hi |= (v & 0xffu) << (8 * (k - 4));
+        }
+        uint8_t *d = out + i;
+        if ((((uintptr_t)d) & 7u) == 0) {
+            __builtin_nontemporal_store(((unsigned long long)hi << 32) | lo, reinterpret_cast<unsigned long long *>(d));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = (uint8_t)((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4))));
+        }
     }
+    for (long long i = a0 + 8 * chunks + threadIdx.x; i < stop; i += blockDim.x)
+        __builtin_nontemporal_store((uint8_t)resolve(sym[i], i), out + i);
 }
 
 // Device stage for a batch of independent streams in ONE set of launches (inflate_many.hip).  The streams sit one
