@@ -117,30 +117,15 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
     };
     put(P0, fetch(P0));
     put(P0 + 1024u, fetch(P0 + 1024u));
-    uint32_t chunk = fetch(P0 + 2048u);
+    uint32_t chunk = fetch(P0 + 2048u);              // stored at the top of the FIRST batch: [P0 + 2048, P0 + 3072)
     __syncthreads();
 
-    int since_refresh = 0;
-    for (uint32_t P = P0; P < n; P += kRowBatch) {
-        if (P != P0) {
-            put(P + kRingAhead, chunk);             // [P + 1024, P + 2048): visible after the insert barriers below
-            chunk = fetch(P + kRingAhead + 1024u);
-        }
-        const uint32_t p = P + (uint32_t)t;
-        if (P < first) {                            // priming: enter the positions, nothing else
-            const bool can = p + kLzMinMatch <= n;
-            uint32_t row, tag;
-            row_key(ring_u32(sh.ring, p & (kRingBytes - 1u)), row, tag);
-            rows_insert(&sh, can, row, tag, p, __builtin_amdgcn_readfirstlane(t >> 6));
-            continue;
-        }
-        const bool refresh = since_refresh >= kRefreshBatches;
-        since_refresh = refresh ? 1 : since_refresh + 1;
-        unsigned long long starts;
-        const RowsToken r = rows_batch(n, P, P0, &sh, t, max_cand, refresh, &starts);
+    // the tokens of a finished batch: bitmap word, distances, histogram
+    auto emit_tokens = [&](uint32_t Pb, const RowsToken &r, unsigned long long starts) __attribute__((always_inline)) {
+        const uint32_t p = Pb + (uint32_t)t;
         const unsigned long long matches = __ballot(r.kind == 2u);
         if (lane == 0) {
-            bm[(P - first) / 64u + (uint32_t)(t >> 6)] = starts;
+            bm[(Pb - first) / 64u + (uint32_t)(t >> 6)] = starts;
             const uint32_t nt = (uint32_t)__popcll(starts), nm = (uint32_t)__popcll(matches);
             if (nt) atomicAdd(&sh.tot_l, nt);
             if (nm) atomicAdd(&sh.tot_d, nm);
@@ -155,11 +140,67 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
         } else if (r.kind == 1u) {
             atomicAdd(&sh.hist_l[sh.ring[p & (kRingBytes - 1u)]], 1u);
         }
+    };
+
+    // Two batches in flight: the compares of batch P (LDS-bound) run beside the parse of the batch before it (VALU-bound);
+    // waves 4-7 and 12-15 take the two in the opposite order, so every SIMD has both kinds of work at any time.
+    const int wave_id = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool parse_first = ((wave_id >> 2) & 1) != 0;
+    int since_refresh = 0;
+    bool have_prev = false;
+    uint32_t P_prev = 0;
+    RowsMatch prev;
+    prev.L = prev.dist = prev.val = 0;
+    for (uint32_t P = P0;; P += kRowBatch) {
+        const bool live = P < n;                    // one more round after the last batch: its parse
+        if (!live && !have_prev) break;
+        if (live) {
+            put(P + kRingAhead, chunk);             // [P + 2048, P + 3072): what the NEXT batch reads beyond its own positions
+            chunk = fetch(P + kRingAhead + 1024u);
+        }
+        const uint32_t p = P + (uint32_t)t;
+        if (live && P < first) {                    // priming: enter the positions, nothing else
+            const bool can = p + kLzMinMatch <= n;
+            uint32_t row, tag;
+            row_key(ring_u32(sh.ring, p & (kRingBytes - 1u)), row, tag);
+            rows_insert(&sh, can, row, tag, p, wave_id);
+            continue;
+        }
+        RowsFront f;
+        uint32_t cover_in;
+        if (live) {
+            const bool refresh = since_refresh >= kRefreshBatches;
+            since_refresh = refresh ? 1 : since_refresh + 1;
+            rows_front(n, P, &sh, t, refresh, f, &cover_in);
+        } else {
+            rows_barrier();
+            cover_in = sh.cover;
+        }
+        RowsMatch cur;
+        cur.L = cur.dist = cur.val = 0;
+        uint32_t CH = 1u;
+#pragma nounroll
+        for (int ph = 0; ph < 2; ++ph) {            // ONE copy of each piece in the code, the order a run-time matter
+            if ((ph == 0) == parse_first) {
+                if (have_prev) CH = rows_parse(n, P_prev, &sh, t, prev);
+            } else if (live) {
+                cur = rows_compare(n, P, P0, &sh, t, max_cand, f);
+            }
+        }
+        if (have_prev) {
+            unsigned long long starts;
+            const RowsToken r = rows_finish(n, P_prev, &sh, t, CH, prev.dist, cover_in, &starts);
+            emit_tokens(P_prev, r, starts);
+        }
 #ifdef ZR_ROWS_STAMPS
         if (lane == 0) sh.stamps[t >> 6][8] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 3 && stamp_out && lane < 9 && P >= first + 64u * kRowBatch && P < first + 96u * kRowBatch)
+        if (blockIdx.x == 3 && stamp_out && lane < 9 && live && P >= first + 64u * kRowBatch && P < first + 96u * kRowBatch)
             stamp_out[(((P - first) / kRowBatch - 64u) * kRowWaves + (uint32_t)(t >> 6)) * 9u + (uint32_t)lane] = sh.stamps[t >> 6][lane];
 #endif
+        if (!live) break;
+        prev = cur;
+        P_prev = P;
+        have_prev = true;
     }
     __syncthreads();
     if (t < kHistWords) hist_out[(size_t)blockIdx.x * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];

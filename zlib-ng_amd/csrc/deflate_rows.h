@@ -37,7 +37,9 @@ constexpr int      kRowBatch = 64 * kRowWaves;
 constexpr int      kRows = 3584;                   // 7 x 512: what fits beside ring and tables in 160 KiB
 constexpr int      kRowEnt = 8;
 constexpr uint32_t kRingBytes = 65536u, kRingMirror = 512u;
-constexpr uint32_t kRingAhead = 1024u;             // plaintext kept beyond the end of the running batch
+constexpr uint32_t kRingAhead = 2048u;             // the ring is filled this far beyond the START of the running batch before the
+                                                   // batch begins: a batch reads up to 1024 + 258 + 16 bytes beyond its start, and
+                                                   // a chunk stored during a batch must not be something that batch reads
 constexpr uint32_t kNiceLen = 64u;                 // a candidate this long ends the search (nice_match, deflate.c:163: 128)
 constexpr uint32_t kCostBit = 16u;                 // cost units per bit
 constexpr uint32_t kCostBias = 1u << 17;           // keeps the (negative) credit for bytes beyond a region positive
@@ -69,6 +71,12 @@ struct RowShared {
 static_assert(sizeof(RowShared) <= 160 * 1024, "RowShared must fit the CU's LDS");
 
 typedef uint32_t u32_lds_unaligned __attribute__((aligned(1)));
+
+// Workgroup barrier that orders LDS traffic only: nothing the workgroup exchanges goes through global memory, and
+// __syncthreads() would also wait for the plaintext prefetch and the token stores in flight (vmcnt).
+__device__ __forceinline__ void rows_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ uint32_t ring_u32(const uint8_t *ring, uint32_t idx) {      // idx < kRingBytes + mirror - 3
     return *reinterpret_cast<const u32_lds_unaligned *>(ring + idx);
@@ -218,50 +226,74 @@ __device__ __forceinline__ void rows_dp_step(uint32_t L, uint32_t LIT6, uint32_t
     W = wave_shift_up1(W, m);
 }
 
-// One batch of kRowBatch positions starting at P; the ring holds every byte of [max(P0, P - 32768), P + batch + kRingAhead)
-// that lies below n, P0 = the first position that was ever loaded.  Returns this lane's token; the region's token-start
-// mask goes to *starts.  `refresh`: recompute the symbol costs from the histogram first.
-__device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t P0, RowShared *sh, int t, uint32_t max_cand,
-                                                bool refresh, unsigned long long *starts) {
+// ---- one batch, in three pieces so that the kernel can software-pipeline them ----------------------------------------------
+// The candidate compares of a batch are bound by LDS throughput (unaligned 16-byte reads at random addresses), its parse by
+// vector-instruction issue, and both are per-wave work without a barrier between them.  Run one after the other in every
+// wave (round 3's first form) each unit idles through the other's phase; so the kernel keeps TWO batches in flight --
+// compares of batch k beside the parse of batch k - 1 -- and half of the waves take them in the opposite order.
+//   rows_front    row image in front of the batch, barrier, ordered insert (16 turns), row image with the batch in it
+//   rows_compare  longest match at this lane's position                                  (LDS-bound)
+//   rows_parse    shortest-path parse of this wave's region of the PREVIOUS batch         (VALU-bound)
+//   rows_finish   exit map, barrier, stitch, path: the previous batch's tokens
+struct RowsFront {                      // what rows_front hands to rows_compare
+    uint2    TA, TC;
+    uint4    PA, PC;
+    uint32_t mine[4];
+    uint32_t before, val, tag;
+    bool     can;
+};
+struct RowsMatch {                      // per lane: what a batch carries from its compares to its parse
+    uint32_t L, dist, val;
+};
+
+// The ring holds every byte of [max(P0, P - 32768), P + kRingAhead) that lies below n, P0 = the first position that
+// was ever loaded.  `refresh`: recompute the symbol costs from the histogram behind the first barrier.  *cover_in = what the
+// previous call's rows_finish left in sh->cover (read at a point no writer can reach).
+__device__ __forceinline__ void rows_front(uint32_t n, uint32_t P, RowShared *sh, int t, bool refresh, RowsFront &f,
+                                           uint32_t *cover_in) {
     const uint8_t *ring = sh->ring;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t p = P + (uint32_t)t;
     const uint32_t pi = p & (kRingBytes - 1u);
-    const bool can = p + kLzMinMatch <= n;               // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
-    const uint32_t val = ring_u32(ring, pi);
-    uint32_t row, tag;
-    row_key(val, row, tag);
-
+    f.can = p + kLzMinMatch <= n;                        // lookahead >= WANT_MIN_MATCH, deflate_quick.c:88
+    f.val = ring_u32(ring, pi);
+    uint32_t row;
+    row_key(f.val, row, f.tag);
     ZR_STAMP(0);
-    // A. the row as it is in front of this batch
-    const uint2 TA = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
-    const uint4 PA = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
-    __syncthreads();
-    const uint32_t cover_in = sh->cover;                 // written by the previous batch in front of this barrier
+    // A. the row as it is in front of this batch, this lane's own 16 bytes, the bytes in front of them
+    f.TA = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
+    f.PA = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.mine[j] = ring_u32(ring, pi + 4u * j);
+    f.before = ring_u32(ring, (pi - 1u) & (kRingBytes - 1u));
+    rows_barrier();
+    *cover_in = sh->cover;                               // written by the previous rows_finish in front of this barrier
     if (refresh) rows_refresh_costs(sh, t);              // its readers come behind the insert turns' barriers
     ZR_STAMP(1);
     // B. insert, waves in position order
-    rows_insert(sh, can, row, tag, p, wave);
+    rows_insert(sh, f.can, row, f.tag, p, wave);
     ZR_STAMP(2);
     // C. the row with the batch in it: only entries inside the batch and below p are news
-    const uint2 TC = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
-    const uint4 PC = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
+    f.TC = *reinterpret_cast<const uint2 *>(&sh->tag[row * kRowEnt]);
+    f.PC = *reinterpret_cast<const uint4 *>(&sh->pos[row * kRowEnt]);
+}
 
-    // ---- longest match at every position --------------------------------------------------------------------------
+__device__ __forceinline__ RowsMatch rows_compare(uint32_t n, uint32_t P, uint32_t P0, const RowShared *sh, int t,
+                                                  uint32_t max_cand, const RowsFront &f) {
+    const uint8_t *ring = sh->ring;
+    const uint32_t p = P + (uint32_t)t;
+    const uint32_t pi = p & (kRingBytes - 1u);
     const uint32_t maxlen = p < n ? ((n - p) < kStdMaxMatch ? (n - p) : kStdMaxMatch) : 0u;
     uint32_t best = 3, dist = 0;                         // a match must reach WANT_MIN_MATCH to count
-    if (can) {
+    if (f.can) {
         const uint32_t back = p - P0;                    // bytes of history the ring really holds
         const uint32_t dmax = back < kLzMaxDist ? back : kLzMaxDist;
         uint32_t dC[4], dA[4];
         const uint32_t tC = (uint32_t)t < dmax ? (uint32_t)t : dmax;
-        uint32_t mC = rows_candidates(TC, PC, tag, p, tC, dC);
-        uint32_t mA = rows_candidates(TA, PA, tag, p, dmax, dA);
-        uint32_t mine[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mine[j] = ring_u32(ring, pi + 4u * j);
-        uint32_t tail_off = 0, want_tail = mine[0];      // the 4 bytes that end at `best` must agree (match_tpl.h:141-173)
+        uint32_t mC = rows_candidates(f.TC, f.PC, f.tag, p, tC, dC);
+        uint32_t mA = rows_candidates(f.TA, f.PA, f.tag, p, dmax, dA);
+        uint32_t tail_off = 0, want_tail = f.mine[0];    // the 4 bytes that end at `best` must agree (match_tpl.h:141-173)
         bool done = false;
         uint32_t budget = max_cand;
 
@@ -275,7 +307,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
             uint32_t l = 16;
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
-                const uint32_t x = cw[j] ^ mine[j];
+                const uint32_t x = cw[j] ^ f.mine[j];
                 if (x) l = 4u * (uint32_t)j + ((uint32_t)(__ffs((int)x) - 1) >> 3);
             }
             if (l >= 16u && maxlen > 16u) {
@@ -295,7 +327,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         };
 
         // a run (distance 1) first: every position of a run lands in ONE row, which keeps only the last few of them
-        if (p > P0 && ring_u32(ring, (pi - 1u) & (kRingBytes - 1u)) == val) consider(1u);
+        if (p > P0 && f.before == f.val) consider(1u);
         while (mC && !done && budget) {
             const uint32_t e = (uint32_t)__ffs((int)mC) - 1u;
             mC &= mC - 1u;
@@ -315,18 +347,27 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         if (best >= kNiceLen && best < maxlen)           // the probe saturated: measure the rest
             best = ring_common_prefix(ring, pi, (pi - dist) & (kRingBytes - 1u), best, maxlen);
     }
+    RowsMatch m;
+    m.L = best >= kLzMinMatch ? best : 0u;
+    m.dist = dist;
+    m.val = f.val;
+    return m;
+}
 
-    ZR_STAMP(3);
-    // ---- shortest-path parse of this wave's region [w0, w0 + lim) ---------------------------------------------------
+// shortest-path parse of this wave's region [w0, w0 + lim) of the batch at P: returns CH (lane i: length of the token the
+// best path takes at region position i)
+__device__ __forceinline__ uint32_t rows_parse(uint32_t n, uint32_t P, const RowShared *sh, int t, const RowsMatch &m) {
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t w0 = P + 64u * (uint32_t)wave;
     const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);        // wave-uniform
-    const uint32_t L = best >= kLzMinMatch ? best : 0u;
-    uint32_t LIT = sh->cost_l[val & 0xffu], DC = 0, FULL = 0;
+    const uint32_t L = m.L;
+    uint32_t LIT = sh->cost_l[m.val & 0xffu], DC = 0, FULL = 0;
     if (L) {
         uint32_t sy, eb;
         rows_len_symbol(L, sy, eb);
         FULL = sh->cost_l[sy] + kCostBit * eb;
-        rows_dist_symbol(dist, sy, eb);
+        rows_dist_symbol(m.dist, sy, eb);
         DC = sh->cost_d[sy] + kCostBit * eb;
     }
     uint32_t LC;                                         // lane j: cost of a match of length j + 1, lane id in the low bits
@@ -335,7 +376,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         rows_len_symbol((uint32_t)lane + 1u < 3u ? 3u : (uint32_t)lane + 1u, sy, eb);
         LC = (uint32_t)lane < 3u ? 0x7fffffffu : (((sh->cost_l[sy] + kCostBit * eb) << 6) | (uint32_t)lane);
     }
-    uint32_t CH = 1u;                                    // lane i: length of the token the best path takes at position i
+    uint32_t CH = 1u;
     if (lim) {
         // positions at or beyond lim (the segment's end inside this region) cost what the credit gives: the recurrence then
         // needs no special case for a short region and runs its 64 steps unrolled, every lane index an immediate
@@ -349,6 +390,17 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
 #undef ZR_DP8
 #undef ZR_DP1
     }
+    return CH;
+}
+
+// the tokens of the batch at P from its parse: exit maps, one barrier, stitch from `cover_in`, this wave's path.  Leaves the
+// next batch's cover in sh->cover.  Returns this lane's token; the region's token-start mask goes to *starts.
+__device__ __forceinline__ RowsToken rows_finish(uint32_t n, uint32_t P, RowShared *sh, int t, uint32_t CH, uint32_t dist,
+                                                 uint32_t cover_in, unsigned long long *starts) {
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t w0 = P + 64u * (uint32_t)wave;
+    const uint32_t lim = w0 >= n ? 0u : ((n - w0) < 64u ? (n - w0) : 64u);
     ZR_STAMP(4);
     // exit map: where does the path through position i leave the region?  pointer doubling over next[i] = i + CH[i]
     {
@@ -361,10 +413,9 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
         }
         sh->exitmap[t] = (uint16_t)(64u * (uint32_t)wave + J);
     }
-    __syncthreads();
-
+    rows_barrier();
     ZR_STAMP(5);
-    // stitch: follow the exits of the regions in front of this one from where the previous batch ended
+    // stitch: follow the exits of the regions in front of this one from where the batch before ended
     const uint32_t nrel = n - P;                          // n > P for every batch that runs
     uint32_t s = cover_in - P;
     for (int r = 0; r < wave; ++r) {
@@ -379,7 +430,7 @@ __device__ __forceinline__ RowsToken rows_batch(uint32_t n, uint32_t P, uint32_t
             mask |= 1ull << q;
             q += (uint32_t)__builtin_amdgcn_readlane((int)CH, (int)q);
         }
-        // where the batch's path ends = the next batch's cover (read there behind its first barrier)
+        // where the batch's path ends = the next batch's cover (read there behind a rows_front barrier)
         if (wave == kRowWaves - 1 && lane == 0)
             sh->cover = P + (s < 64u * (uint32_t)(wave + 1) && s < nrel ? 64u * (uint32_t)wave + q : s);
     }
