@@ -74,7 +74,7 @@ def test_ratio_is_level6_class(mods):
 
 
 def test_block_type_choice(mods):
-    """zng_tr_flush_block's choice (trees.c:660-719) per segment: incompressible bytes are STORED (5 bytes per 65535),
+    """zng_tr_flush_block's choice (trees.c:660-719) per block: incompressible bytes are STORED (5 bytes per block),
     a few bytes take the STATIC code set, ordinary data a dynamic block.  BTYPE is bits 1-2 of a block's first byte."""
     zr, dfl, inf = mods
     torch = torch_mod()
@@ -90,18 +90,19 @@ def test_block_type_choice(mods):
         assert dec.status == 1 and inf.resolve_dev(dec).cpu().numpy().tobytes() == data
         return comp
 
-    noise = rng.integers(0, 256, size=(1 << 20) + 777, dtype=np.uint8).tobytes()     # two full segments + a tail
+    noise = rng.integers(0, 256, size=(1 << 20) + 777, dtype=np.uint8).tobytes()     # several segments, a block per 60 KiB
     comp = run(noise)
     pos = payload = nblocks = 0                                         # nothing but stored blocks ...
     while pos < len(comp) - 2:
         ln = int.from_bytes(comp[pos + 1:pos + 3], "little")
-        assert comp[pos] == 0 and int.from_bytes(comp[pos + 3:pos + 5], "little") == ln ^ 0xffff
+        assert comp[pos] == 0 and int.from_bytes(comp[pos + 3:pos + 5], "little") == ln ^ 0xffff and ln <= 65535
         pos += 5 + ln
         payload += ln
         nblocks += 1
     assert payload == len(noise) and comp[pos:] == b"\x03\x00"           # ... and the final empty static block
-    assert nblocks <= len(noise) // 65535 + 2 * (len(noise) // (128 << 10) + 1)   # segments are >= 128 KiB
-    assert comp[1:3] == (65535).to_bytes(2, "little")
+    # a block per 61440 positions, each followed by the empty stored block that byte-aligns it
+    assert nblocks <= 2 * (len(noise) // 61440 + len(noise) // (128 << 10) + 2)
+    assert comp[1:3] == (61440).to_bytes(2, "little")
     for data in (b"", b"q", b"abcabcabcabc"):
         comp = run(data)
         assert (comp[0] >> 1) & 3 == 1, data                              # static

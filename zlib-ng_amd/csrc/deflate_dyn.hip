@@ -46,6 +46,22 @@ struct SegJob {
     uint32_t       stream;      // row of the per-stream result table; 0x80000000 set on the stream's last segment
 };
 
+// one BLOCK of the output (K2 .. K4): the tokens of its segment that start in [blo, bhi)
+struct BlkJob {
+    const uint8_t *in;        // stream base (position 0)
+    uint8_t       *out;       // this block's output slot (4-byte aligned)
+    uint8_t       *dst;       // the stream's output buffer (what K4 packs into)
+    uint64_t       dst_cap;
+    uint64_t       bm_off, d16_off;       // its segment's token scratch
+    uint32_t       seg_start, seg_end;    // its segment
+    uint32_t       blo, bhi;
+    uint32_t       hist_idx, hist_prev;   // histogram snapshot of this block's end; 1 if the snapshot before it is the block's begin
+    uint32_t       out_cap;
+    uint32_t       is_last;               // the block that carries BFINAL
+    uint32_t       first_seg;             // index of the first BLOCK of this block's stream
+    uint32_t       stream;                // row of the per-stream result table; 0x80000000 set on the stream's last block
+};
+
 constexpr uint32_t kSegBytes = 512u << 10;     // plaintext per segment / per dynamic block: the largest, and ...
 constexpr uint32_t kSegBytesMin = 128u << 10;  // ... the smallest.  A segment is one workgroup and one CU holds one
                                                // workgroup, so a stream is cut into at least ~2 segments per CU when
@@ -57,7 +73,14 @@ static uint32_t segment_bytes(size_t in_len, int cus) {
     return seg;
 }
 constexpr uint32_t kPrime = 32768u;            // dictionary primed from the previous segment
-constexpr int      kHistWords = 320;           // 288 literal/length + 32 distance counts per segment
+constexpr int      kHistWords = 320;           // 288 literal/length + 32 distance counts
+// A segment is written as several BLOCKS, one per kSubBytes of positions (counted from the segment's first batch): zlib's
+// blocks hold about as much (lit_bufsize 16384 symbols), the codes follow the data more closely, a block may be stored
+// (<= 65535 bytes), and -- what it was done for -- every block start is a place where a parallel inflater can cut the
+// stream (inflate_large.hip, inflate_threads.cpp): one block per 512 KiB segment gave a 256 MiB stream 434 parts.
+constexpr uint32_t kSubBatches = 60;
+constexpr uint32_t kSubBytes = kSubBatches * kRowBatch;          // 61440
+constexpr uint32_t kMaxSub = (kSegBytes + kRowBatch + kSubBytes - 1) / kSubBytes + 1;      // histogram snapshots per segment
 
 // scratch a segment of `bytes` plaintext bytes needs: bitmap words / distance entries (its first batch may start up to
 // one batch in front of the segment)
@@ -146,7 +169,8 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
     // waves 4-7 and 12-15 take the two in the opposite order, so every SIMD has both kinds of work at any time.
     const int wave_id = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool parse_first = ((wave_id >> 2) & 1) != 0;
-    int since_refresh = 0;
+    int since_refresh = 0, snap_due = -1;            // a histogram snapshot (sub-block index) to write once every wave's counts are in
+    uint32_t *hist_seg = hist_out + (size_t)blockIdx.x * kMaxSub * kHistWords;
     bool have_prev = false;
     uint32_t P_prev = 0;
     RowsMatch prev;
@@ -176,6 +200,10 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
             rows_barrier();
             cover_in = sh.cover;
         }
+        if (snap_due >= 0) {                        // the barriers above are behind the last batch's histogram updates
+            if (t < kHistWords) hist_seg[(size_t)snap_due * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];
+            snap_due = -1;
+        }
         RowsMatch cur;
         cur.L = cur.dist = cur.val = 0;
         uint32_t CH = 1u;
@@ -191,6 +219,8 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
             unsigned long long starts;
             const RowsToken r = rows_finish(n, P_prev, &sh, t, CH, prev.dist, cover_in, &starts);
             emit_tokens(P_prev, r, starts);
+            const uint32_t done_batches = (P_prev - first) / kRowBatch + 1u;
+            if (done_batches % kSubBatches == 0) snap_due = (int)(done_batches / kSubBatches) - 1;
         }
 #ifdef ZR_ROWS_STAMPS
         if (lane == 0) sh.stamps[t >> 6][8] = __builtin_amdgcn_s_memtime();
@@ -203,7 +233,11 @@ void lz_rows_kernel(const SegJob *__restrict__ jobs, unsigned long long *__restr
         have_prev = true;
     }
     __syncthreads();
-    if (t < kHistWords) hist_out[(size_t)blockIdx.x * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];
+    {                                                // the totals: the last sub-block's snapshot
+        const uint32_t span = n - first;
+        const uint32_t nsub = span ? (span + kSubBytes - 1) / kSubBytes : 1u;
+        if (t < kHistWords) hist_seg[(size_t)(nsub - 1u) * kHistWords + t] = t < 288 ? sh.hist_l[t] : sh.hist_d[t - 288];
+    }
 }
 
 // ---- dynamic Huffman ---------------------------------------------------------------------------------------
@@ -394,7 +428,7 @@ __device__ __forceinline__ uint32_t next_start_rel(const unsigned long long *bm,
 }
 
 __global__ __launch_bounds__(256)
-void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long long *__restrict__ bm_base,
+void emit_dynamic_kernel(const BlkJob *__restrict__ jobs, const unsigned long long *__restrict__ bm_base,
                          const uint16_t *__restrict__ d16_base, const uint32_t *__restrict__ hist_in,
                          uint32_t *__restrict__ seg_len) {
     __shared__ DynTables T;
@@ -402,19 +436,31 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long lo
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t sh_cw, sh_cbits, sh_wbase;
 
-    const SegJob job = jobs[blockIdx.x];
+    const BlkJob job = jobs[blockIdx.x];
     const uint8_t *in = job.in;
-    const uint32_t lo = job.seg_start, hi = job.seg_end;
-    const uint32_t first = lo - lo % kRowBatch;              // position of bit 0 of the segment's bitmap
+    const uint32_t first = job.seg_start - job.seg_start % kRowBatch;      // position of bit 0 of the segment's bitmap
     const unsigned long long *bm = bm_base + job.bm_off;
     const uint16_t *d16 = d16_base + job.d16_off;
-    const uint32_t hi_rel = hi - first;
+    const uint32_t hi_rel = job.seg_end - first;
+    // The tokens that START in [blo, bhi) are this block's; the bytes they cover are [lo, hi): the last token may reach
+    // beyond bhi, and the first bytes of the range may still belong to the block before.
+    uint32_t lo = job.blo, hi = job.bhi;
+    if (lo < hi) {
+        const uint32_t r0 = lo - first;
+        lo = ((bm[r0 >> 6] >> (r0 & 63u)) & 1ull) ? lo : first + next_start_rel(bm, r0, hi_rel);
+        hi = first + next_start_rel(bm, job.bhi - 1u - first, hi_rel);
+        if (lo > hi) lo = hi;
+    }
+    const uint32_t tok_hi = job.bhi;                         // token starts at or beyond this are the next block's
     uint32_t *outw = reinterpret_cast<uint32_t *>(job.out);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     // 1. histogram: counted by K1 while it chose the tokens
-    for (int i = t; i < 288; i += 256) T.lfreq[i] = hist_in[(size_t)blockIdx.x * kHistWords + i] + (i == 256 ? 1u : 0u);   // + end-of-block
-    if (t < 32) T.dfreq[t] = hist_in[(size_t)blockIdx.x * kHistWords + 288 + t];
+    {
+        const uint32_t *now = hist_in + (size_t)job.hist_idx * kHistWords, *was = job.hist_prev ? now - kHistWords : nullptr;
+        for (int i = t; i < 288; i += 256) T.lfreq[i] = now[i] - (was ? was[i] : 0u) + (i == 256 ? 1u : 0u);     // + end-of-block
+        if (t < 32) T.dfreq[t] = now[288 + t] - (was ? was[288 + t] : 0u);
+    }
     __syncthreads();
     for (int i = t; i < 288; i += 256) T.lfreq0[i] = T.lfreq[i];
     if (t < 32) T.dfreq0[t] = T.dfreq[t];
@@ -596,7 +642,7 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long lo
         // the token starts among this lane's 16 positions, and 48 bits of look-ahead for their lengths
         unsigned long long win = 0;
         const uint32_t rel0 = p0 - first;
-        if (p0 < hi) {
+        if (p0 < tok_hi) {
             const uint32_t sft = rel0 & 63u;
             win = bm[rel0 >> 6] >> sft;
             if (sft) win |= bm[(rel0 >> 6) + 1] << (64u - sft);
@@ -605,7 +651,7 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long lo
         for (int j = 0; j < kDynPer; ++j) {
             const uint32_t p = p0 + (uint32_t)j;
             c1[j] = n1[j] = c2[j] = n2[j] = 0;
-            if (p < hi && ((win >> j) & 1ull)) {
+            if (p < tok_hi && ((win >> j) & 1ull)) {
                 const unsigned long long ahead = win >> (j + 1);
                 uint32_t nx = ahead ? rel0 + (uint32_t)j + 1u + (uint32_t)__builtin_ctzll(ahead)
                                     : next_start_rel(bm, rel0 + 63u, hi_rel);      // a match that outruns the window
@@ -693,7 +739,7 @@ void emit_dynamic_kernel(const SegJob *__restrict__ jobs, const unsigned long lo
 // plus the per-stream totals and the out_cap check.  One workgroup; `excl` = nseg + 1 u64 of scratch.
 //   results[2 * s] = compressed size of stream s, results[2 * s + 1] = 1 if it does not fit its buffer
 __global__ __launch_bounds__(1024)
-void segments_scan_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len, uint32_t nseg,
+void segments_scan_kernel(const BlkJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len, uint32_t nseg,
                           unsigned long long *__restrict__ excl, unsigned long long *__restrict__ dst_off,
                           unsigned long long *__restrict__ results) {
     __shared__ unsigned long long wave_sum[16];
@@ -722,7 +768,7 @@ void segments_scan_kernel(const SegJob *__restrict__ jobs, const uint32_t *__res
     if (t == 0) excl[nseg] = carry;
     __syncthreads();                                     // one workgroup: its own global stores are visible to it
     for (uint32_t k = (uint32_t)t; k < nseg; k += 1024u) {
-        const SegJob &j = jobs[k];
+        const BlkJob &j = jobs[k];
         const unsigned long long off = excl[k] - excl[j.first_seg];
         dst_off[k] = off;
         if (j.stream & 0x80000000u) {
@@ -737,9 +783,9 @@ void segments_scan_kernel(const SegJob *__restrict__ jobs, const uint32_t *__res
 // K4: pack the segments back to back (byte granular); a stream that does not fit its buffer is cut at the buffer's end
 // (K3 has flagged it)
 __global__ __launch_bounds__(256)
-void gather_segments_kernel(const SegJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len,
+void gather_segments_kernel(const BlkJob *__restrict__ jobs, const uint32_t *__restrict__ seg_len,
                             const unsigned long long *__restrict__ dst_off) {
-    const SegJob job = jobs[blockIdx.y];
+    const BlkJob job = jobs[blockIdx.y];
     const unsigned long long off = dst_off[blockIdx.y];
     unsigned long long n = seg_len[blockIdx.y];
     if (off >= job.dst_cap) return;
@@ -803,65 +849,104 @@ static int deflate_rows_enqueue(int level, const zng_rocm_stream_job *sjobs, siz
                                 unsigned long long *d_results_copy = nullptr) {
     size_t nseg = 0;
     for (size_t s = 0; s < njobs; ++s) nseg += sjobs[s].in_len ? ((size_t)sjobs[s].in_len + seg_bytes - 1) / seg_bytes : 1;
+    const size_t max_blk = nseg * kMaxSub;
     SegJob *d_jobs = nullptr, *jobs = nullptr;
+    BlkJob *d_blk = nullptr, *blk = nullptr;
     uint32_t *d_seg_len = nullptr, *d_hist = nullptr;
     unsigned long long *d_scan = nullptr, *d_bm = nullptr, *d_res = nullptr, *h_res = nullptr;
     uint16_t *d_d16 = nullptr;
     uint8_t *d_slots = nullptr;
     if (int rc = host_tables_acquire(ws)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynJobsHost, nseg * sizeof(SegJob), true, (void **)&jobs)) return rc;
+    // pinned: SegJob[nseg] | BlkJob[max_blk]
+    const size_t seg_tab = (nseg * sizeof(SegJob) + 255) & ~(size_t)255;
+    if (int rc = scratch_reserve(ws, kScrDynJobsHost, seg_tab + max_blk * sizeof(BlkJob), true, (void **)&jobs)) return rc;
+    blk = reinterpret_cast<BlkJob *>(reinterpret_cast<uint8_t *>(jobs) + seg_tab);
     if (int rc = scratch_reserve(ws, kScrDynSegLenHost, njobs * 2 * sizeof(unsigned long long), true, (void **)&h_res)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynJobs, nseg * sizeof(SegJob), false, (void **)&d_jobs)) return rc;
-    if (int rc = scratch_reserve(ws, kScrDynSegLen, nseg * (sizeof(uint32_t) + kHistWords * sizeof(uint32_t)), false, (void **)&d_seg_len))
+    if (int rc = scratch_reserve(ws, kScrDynJobs, seg_tab + max_blk * sizeof(BlkJob), false, (void **)&d_jobs)) return rc;
+    d_blk = reinterpret_cast<BlkJob *>(reinterpret_cast<uint8_t *>(d_jobs) + seg_tab);
+    if (int rc = scratch_reserve(ws, kScrDynSegLen, max_blk * sizeof(uint32_t) + 64 + nseg * (size_t)kMaxSub * kHistWords * sizeof(uint32_t), false, (void **)&d_seg_len))
         return rc;
-    d_hist = d_seg_len + ((nseg + 3) & ~(size_t)3);
-    if (int rc = scratch_reserve(ws, kScrDynDstOff, (2 * nseg + 2 + 2 * njobs) * sizeof(unsigned long long), false, (void **)&d_scan))
+    d_hist = d_seg_len + ((max_blk + 3) & ~(size_t)3);
+    if (int rc = scratch_reserve(ws, kScrDynDstOff, (2 * max_blk + 2 + 2 * njobs) * sizeof(unsigned long long), false, (void **)&d_scan))
         return rc;
-    unsigned long long *d_excl = d_scan, *d_dst_off = d_scan + nseg + 1;
-    d_res = d_dst_off + nseg + 1;
-    size_t slot_total = 0, bm_total = 0, d16_total = 0, k = 0;
+    size_t slot_total = 0, bm_total = 0, d16_total = 0, k = 0, nb = 0;
     for (size_t s = 0; s < njobs; ++s) {
         const zng_rocm_stream_job &j = sjobs[s];
         const uint32_t dict = j.dict_len;
         const bool final_block = (j.flags & ZNG_ROCM_BLOCK_NOT_FINAL) == 0;
         const size_t n = j.in_len ? ((size_t)j.in_len + seg_bytes - 1) / seg_bytes : 1;
-        const size_t k0 = k;
+        const size_t b0 = nb;
         for (size_t i = 0; i < n; ++i, ++k) {
             // positions count from the first dictionary byte: the segments' own 32 KiB priming reaches into it
             const uint32_t a = dict + (uint32_t)(i * seg_bytes);
             const uint32_t b = dict + (uint32_t)((i + 1) * (size_t)seg_bytes < j.in_len ? (i + 1) * (size_t)seg_bytes : j.in_len);
             jobs[k].in = (const uint8_t *)j.in - dict;
+            jobs[k].out = nullptr;
             jobs[k].dst = (uint8_t *)j.out;
-            jobs[k].dst_cap = cap_override && s == 0 ? *cap_override : j.out_cap;
+            jobs[k].dst_cap = 0;
             jobs[k].seg_start = a;
             jobs[k].seg_end = b;
-            jobs[k].out_cap = (uint32_t)seg_slot_bytes(b - a);
-            jobs[k].is_last = (i + 1 == n && final_block) ? 1 : 0;
-            jobs[k].first_seg = (uint32_t)k0;
-            jobs[k].stream = (uint32_t)s | (i + 1 == n ? 0x80000000u : 0u);
-            jobs[k].out = (uint8_t *)slot_total;          // offset for now
+            jobs[k].out_cap = 0;
+            jobs[k].is_last = 0;
+            jobs[k].first_seg = 0;
+            jobs[k].stream = (uint32_t)s;
             jobs[k].bm_off = bm_total;
             jobs[k].d16_off = d16_total;
-            slot_total += jobs[k].out_cap;
+            // the segment's blocks: one per kSubBytes of positions counted from its first batch (the matcher snapshots
+            // its histogram at the same places); a block without positions of its own is left out
+            const uint32_t first = a - a % kRowBatch;
+            const uint32_t nsub = b > first ? (b - first + kSubBytes - 1) / kSubBytes : 1u;
+            bool prev_written = false;
+            for (uint32_t sub = 0; sub < nsub; ++sub) {
+                const uint32_t p0 = first + sub * kSubBytes, p1 = p0 + kSubBytes;
+                const uint32_t blo = p0 > a ? p0 : a, bhi = p1 < b ? p1 : b;
+                if (blo >= bhi && !(b == a && sub + 1 == nsub)) {          // (an empty segment still gets its one block)
+                    prev_written = true;                                  // its snapshot exists all the same
+                    continue;
+                }
+                BlkJob &q = blk[nb++];
+                q.in = jobs[k].in;
+                q.dst = (uint8_t *)j.out;
+                q.dst_cap = cap_override && s == 0 ? *cap_override : j.out_cap;
+                q.bm_off = bm_total;
+                q.d16_off = d16_total;
+                q.seg_start = a;
+                q.seg_end = b;
+                q.blo = blo;
+                q.bhi = bhi;
+                q.hist_idx = (uint32_t)(k * kMaxSub + sub);
+                q.hist_prev = sub > 0 && prev_written ? 1u : 0u;
+                q.out_cap = (uint32_t)seg_slot_bytes(bhi - blo + 258u);
+                q.is_last = 0;
+                q.first_seg = (uint32_t)b0;
+                q.stream = (uint32_t)s;
+                q.out = (uint8_t *)slot_total;            // offset for now
+                slot_total += q.out_cap;
+                prev_written = true;
+            }
             bm_total += seg_bm_words(b - a);
             d16_total += seg_d16_entries(b - a);
         }
+        blk[nb - 1].stream |= 0x80000000u;               // the stream's last block ...
+        blk[nb - 1].is_last = final_block ? 1u : 0u;      // ... carries BFINAL
     }
+    unsigned long long *d_excl = d_scan, *d_dst_off = d_scan + nb + 1;
+    d_res = d_dst_off + nb + 1;
     if (int rc = scratch_reserve(ws, kScrDynSlots, slot_total, false, (void **)&d_slots)) return rc;
     // token scratch of the matcher: 1 bit + half a u16 per position (K1 -> K2)
     if (int rc = scratch_reserve(ws, kScrDynSel, bm_total * sizeof(unsigned long long) + d16_total * sizeof(uint16_t), false, (void **)&d_bm))
         return rc;
     d_d16 = reinterpret_cast<uint16_t *>(d_bm + bm_total);
-    for (size_t i = 0; i < nseg; ++i) jobs[i].out = d_slots + (size_t)jobs[i].out;
-    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, nseg * sizeof(SegJob), hipMemcpyHostToDevice, st));
+    for (size_t i = 0; i < nb; ++i) blk[i].out = d_slots + (size_t)blk[i].out;
+    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, seg_tab + nb * sizeof(BlkJob), hipMemcpyHostToDevice, st));
 
     ZR_LAUNCH_TRACED(lz_rows_kernel, dim3((unsigned)nseg), dim3(kRowBatch), st, d_jobs, d_bm, d_d16, d_hist, kLevelCand[level], g_rows_stamps);
     ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nseg), dim3(256), 0, st, d_jobs, d_bm, d_d16, d_hist, d_seg_len);
+    hipLaunchKernelGGL(emit_dynamic_kernel, dim3((unsigned)nb), dim3(256), 0, st, d_blk, d_bm, d_d16, d_hist, d_seg_len);
     ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(segments_scan_kernel, dim3(1), dim3(1024), 0, st, d_jobs, d_seg_len, (uint32_t)nseg, d_excl, d_dst_off, d_res);
+    hipLaunchKernelGGL(segments_scan_kernel, dim3(1), dim3(1024), 0, st, d_blk, d_seg_len, (uint32_t)nb, d_excl, d_dst_off, d_res);
     ZR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gather_segments_kernel, dim3(njobs > 64 ? 4 : 16, (unsigned)nseg), dim3(256), 0, st, d_jobs, d_seg_len, d_dst_off);
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(njobs > 64 ? 2 : 4, (unsigned)nb), dim3(256), 0, st, d_blk, d_seg_len, d_dst_off);
     ZR_HIP(hipGetLastError());
     if (d_results_copy)
         ZR_HIP(hipMemcpyAsync(d_results_copy, d_res, njobs * 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
