@@ -488,15 +488,17 @@ def run_single_stream_legs(args, zr, torch, dist, dev, world, rank):
                          "value": round(world * gb / t_def, 2), "unit": "GB/s of input", "ms_per_stream": round(t_def * 1e3, 2),
                          "ratio": round(n / clen, 3), "scaling": "replicas only" if world > 1 else "single",
                          "reference_container_GBps": REFERENCE_CONTAINER["deflate_level6_GBps"]},
-        "inflate": {"workload": "configs[2]: raw inflate of that level-6 stream (host, %.1f MiB) into HBM, bit-exact vs the plaintext; "
-                                "host decode on %d threads cut at found block boundaries, device resolve" % (clen / 2**20, T),
-                    "value": round(world * gb / t_inf, 2), "unit": "GB/s of output", "ms_per_stream": round(t_inf * 1e3, 2),
-                    "in_GBps": round(world * clen / 1e9 / t_inf, 2), "host_threads": T, "parts_joined": parts,
-                    "one_host_thread_GBps": round(gb / t_inf1, 2),
-                    "device_only": {"what": "zng_rocm_inflate_large_dev: the stream already in HBM, block starts found on the device, one "
-                                            "wavefront per part, symbols resolved by the context chain; host: sort + chain walk on 1 thread",
-                                    "GBps_of_output": round(world * gb / t_large, 2), "ms_per_stream": round(t_large * 1e3, 2),
-                                    "parts": big["rc"][3], "host_threads": 1},
+        # configs[2]: the stream is resident in HBM when the timed region starts (the bench contract), so the figure is the
+        # device path; the host-pointer path (token decode on host threads, PCIe for the tokens) is reported beside it
+        "inflate": {"workload": "configs[2]: raw inflate of that level-6 stream (%.1f MiB, resident in HBM) into HBM, bit-exact vs the "
+                                "plaintext; zng_rocm_inflate_large_dev: block starts found on the device, one wavefront per part, "
+                                "symbols resolved by the context chain; host: sort + chain walk on 1 thread" % (clen / 2**20),
+                    "value": round(world * gb / t_large, 2), "unit": "GB/s of output", "ms_per_stream": round(t_large * 1e3, 2),
+                    "in_GBps": round(world * clen / 1e9 / t_large, 2), "parts": big["rc"][3], "host_threads": 1,
+                    "host_decode": {"what": "the same stream handed over as a HOST buffer: token decode on %d host threads cut at found "
+                                            "block boundaries, tokens over PCIe, device resolve" % T,
+                                    "GBps_of_output": round(world * gb / t_inf, 2), "ms_per_stream": round(t_inf * 1e3, 2),
+                                    "host_threads": T, "parts_joined": parts, "one_host_thread_GBps": round(gb / t_inf1, 2)},
                     "scaling": "replicas only" if world > 1 else "single",
                     "reference_container_GBps": REFERENCE_CONTAINER["inflate_out_GBps"]},
     }

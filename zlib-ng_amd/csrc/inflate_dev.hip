@@ -35,6 +35,19 @@ namespace zr {
 // stream data is checked against the array it goes into; a violation is counted (zng_rocm_debug_inflate_bounds()) and the
 // index clamped.  Round 2's aperture violation was traced to addressing, not to an index; this build is the
 // evidence that no index leaves its array on the mutated-stream corpus either.
+// Diagnostic builds (-DZR_INFLATE_STATS, tools/micro/inflate_stats.sh): how often the hand-written loop hands a symbol to the
+// general code, and why (zng_rocm_debug_inflate_stats()).
+#ifdef ZR_INFLATE_STATS
+__device__ unsigned long long g_inflate_stats[16];
+__device__ unsigned long long g_inflate_span[2 * 16384];         // per job (the first 16384): s_memtime at its start and end
+#ifdef ZR_INFLATE_STATS_EXITS
+#define ZR_STAT(i) do { if (lane == 0) atomicAdd(&g_inflate_stats[i], 1ull); } while (0)
+#else
+#define ZR_STAT(i) do { } while (0)
+#endif
+#else
+#define ZR_STAT(i) do { } while (0)
+#endif
 #ifdef ZR_INFLATE_BOUNDS
 __device__ unsigned int g_inflate_bounds_violations;
 __device__ __forceinline__ uint32_t zr_idx(uint32_t i, uint32_t n) {
@@ -192,6 +205,203 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     return kBadMark;
 }
 
+// The decode loop's fast paths, hand-written (inffast_tpl.h:151-226 is the loop this stands for).  The parse is
+// wave-uniform and serial: it runs on the CU's one scalar unit, a wave gets an instruction issued every four or five
+// cycles, and a CU holds at most 16 streams (LDS) -- so what counts is the NUMBER of instructions and taken branches per
+// symbol.  The compiler's version of this loop spent 27 scalar instructions on a literal and about 80 on a match, most of
+// them carrying loop-exit conditions around as lane masks; here a root-table literal costs 7 and a short copy about 40.
+// The loop handles, per symbol:
+//   * a refill of the bit buffer from the 64 fetched words (it leaves when the 64 are used up);
+//   * a literal whose code fits the root table: into the waiting run (`lit`, literal j in lane j);
+//   * a length symbol whose code fits the root table + a distance whose code fits its root table, when the copy is one of
+//     the common shapes and nothing else is due (len <= 64, op + len <= oplim: room in `out`, no flush): source in the
+//     ring without overlap (dist <= kNear, dist >= len), source already flushed (dist > kNear: read back from HBM), or
+//     -- parts only -- source in front of the part (ZR_INFLATE_BEFORE_PART).
+// Anything else leaves the loop with `stage` = what has been consumed of the next symbol: 0 nothing, 1 the length (`len`
+// valid), 2 length and distance (`len`, `dist` valid); the C++ code below finishes that symbol in full generality and
+// comes back.  Positions: `opb` is the position of the first waiting literal, op = opb + npend.
+// (A variant that looked both tables up at 64 bit offsets at once -- lane j with the buffer shifted by j, the next
+// symbol's entry then a v_readlane away -- removed two of three table accesses and was no faster for one wave and 12 %
+// slower for 16 per CU: the accesses are not what a symbol waits for.)
+// Hazards (the assembler inserts no wait states into inline asm): on gfx950 a VALU write of an SGPR/VCC needs two
+// instructions before a VALU reads it -- the v_cmp / masked-operation pairs below are spaced accordingly; LDS operations
+// of one wave execute in order, so a ds_read after a ds_write of the same bytes needs no wait.
+#define ZR_INFLATE_FAST_LOOP(RD, WR, GL, BEFORE)                                                                       \
+    "s_mov_b32 s43, 0\n\t"                                                                                             \
+    "L_top_%=:\n\t"                                                                                                    \
+    "s_cmp_gt_u32 %[cnt], 31\n\t"                                                                                      \
+    "s_cbranch_scc1 L_look_%=\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[widx], 64\n\t"                                                                                     \
+    "s_cbranch_scc1 L_exit0_%=\n\t"                                                                                    \
+    "v_readlane_b32 s42, %[cur], %[widx]\n\t"                                                                          \
+    "s_add_u32 %[widx], %[widx], 1\n\t"                                                                                \
+    "s_nop 0\n\t"                                                                                                      \
+    "s_lshl_b64 s[44:45], s[42:43], %[cnt]\n\t"                                                                        \
+    "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"                                                                        \
+    "s_add_u32 %[cnt], %[cnt], 32\n\t"                                                                                 \
+    "L_look_%=:\n\t"                                                                                                   \
+    "v_bfe_u32 %[va], s40, 0, %[litroot]\n\t"                                                                    \
+    "v_lshl_add_u32 %[va], %[va], 1, %[litb]\n\t"                                                                      \
+    "ds_read_u16 %[vb], %[va]\n\t"                                                                                     \
+    "v_cmp_eq_u32 vcc, %[npend], %[lane]\n\t"                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    "v_readfirstlane_b32 %[e], %[vb]\n\t"                                                                              \
+    "v_lshrrev_b32 %[vb], 4, %[vb]\n\t"                                                                                \
+    "s_cmpk_gt_u32 %[e], 0xfff\n\t"                                                                                    \
+    "s_cbranch_scc1 L_notlit_%=\n\t"                                                                                   \
+    "s_and_b32 %[t0], %[e], 15\n\t"                                                                                    \
+    "v_cndmask_b32 %[lit], %[lit], %[vb], vcc\n\t"                                                                     \
+    "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
+    "s_add_u32 %[npend], %[npend], 1\n\t"                                                                              \
+    "s_cmp_lg_u32 %[npend], 64\n\t"                                                                                    \
+    "s_cbranch_scc1 L_top_%=\n\t"                                                                                      \
+    "s_branch L_exit0_%=\n\t"                                                                                          \
+    "L_notlit_%=:\n\t"                                                                                                 \
+    /* e - 0x1010 = code length | (symbol - 257) << 4; symbols 257..285 only (256, 286.., the long and bad marks leave) */ \
+    "s_sub_u32 %[t1], %[e], 0x1010\n\t"                                                                                \
+    "s_cmpk_gt_u32 %[t1], 0x1cf\n\t"                                                                                   \
+    "s_cbranch_scc1 L_exit0_%=\n\t"                                                                                    \
+    "s_and_b32 %[t0], %[e], 15\n\t"                                                                                    \
+    "s_lshr_b32 %[t1], %[t1], 4\n\t"                                                                                   \
+    "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
+    "s_add_u32 %[len], %[t1], 3\n\t"                                                                                   \
+    "s_cmp_lt_u32 %[t1], 8\n\t"                                                                                        \
+    "s_cbranch_scc1 L_havelen_%=\n\t"                                                                                  \
+    "s_movk_i32 %[len], 258\n\t"                                                                                       \
+    "s_cmp_eq_u32 %[t1], 28\n\t"                                                                                       \
+    "s_cbranch_scc1 L_havelen_%=\n\t"                                                                                  \
+    "s_sub_u32 %[t0], %[t1], 4\n\t"                                                                                    \
+    "s_lshr_b32 %[t0], %[t0], 2\n\t"                                                                                   \
+    "s_and_b32 %[t1], %[t1], 3\n\t"                                                                                    \
+    "s_or_b32 %[t1], %[t1], 4\n\t"                                                                                     \
+    "s_lshl_b32 %[t1], %[t1], %[t0]\n\t"                                                                               \
+    "s_bfm_b32 %[len], %[t0], 0\n\t"                                                                                   \
+    "s_and_b32 %[len], %[len], s40\n\t"                                                                                \
+    "s_add_u32 %[len], %[len], %[t1]\n\t"                                                                              \
+    "s_add_u32 %[len], %[len], 3\n\t"                                                                                  \
+    "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
+    "L_havelen_%=:\n\t"                                                                                                \
+    "s_cmp_gt_u32 %[cnt], 31\n\t"                                                                                      \
+    "s_cbranch_scc1 L_dist_%=\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[widx], 64\n\t"                                                                                     \
+    "s_cbranch_scc1 L_exit1_%=\n\t"                                                                                    \
+    "v_readlane_b32 s42, %[cur], %[widx]\n\t"                                                                          \
+    "s_add_u32 %[widx], %[widx], 1\n\t"                                                                                \
+    "s_nop 0\n\t"                                                                                                      \
+    "s_lshl_b64 s[44:45], s[42:43], %[cnt]\n\t"                                                                        \
+    "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"                                                                        \
+    "s_add_u32 %[cnt], %[cnt], 32\n\t"                                                                                 \
+    "L_dist_%=:\n\t"                                                                                                   \
+    "v_bfe_u32 %[va], s40, 0, %[distroot]\n\t"                                                                   \
+    "v_lshl_add_u32 %[va], %[va], 2, %[distb]\n\t"                                                                     \
+    "ds_read_b32 %[vb], %[va]\n\t"                                                                                     \
+    "s_add_u32 %[op], %[opb], %[npend]\n\t"                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    "v_readfirstlane_b32 %[e], %[vb]\n\t"                                                                              \
+    "s_cmp_gt_u32 %[e], 0xffffffe0\n\t"                                                                                \
+    "s_cbranch_scc1 L_exit1_%=\n\t"                                                                                    \
+    "s_and_b32 %[t0], %[e], 15\n\t"                                                                                    \
+    "s_bfe_u32 %[t1], %[e], 0x40004\n\t"                                                                               \
+    "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
+    "s_lshr_b32 %[dist], %[e], 8\n\t"                                                                                  \
+    "s_bfm_b32 %[t0], %[t1], 0\n\t"                                                                                    \
+    "s_and_b32 %[t0], %[t0], s40\n\t"                                                                                  \
+    "s_add_u32 %[dist], %[dist], %[t0]\n\t"                                                                            \
+    "s_lshr_b64 s[40:41], s[40:41], %[t1]\n\t"                                                                         \
+    "s_sub_u32 %[cnt], %[cnt], %[t1]\n\t"                                                                              \
+    /* a copy of at most 64 with nothing else due (room in `out`, no flush)? */                                       \
+    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
+    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    "s_add_u32 %[t1], %[op], %[len]\n\t"                                                                               \
+    "s_cmp_gt_u32 %[t1], %[oplim]\n\t"                                                                                 \
+    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    /* the waiting literals go to the ring: lane j < npend -> position opb + j */                                     \
+    "s_cmp_eq_u32 %[npend], 0\n\t"                                                                                     \
+    "s_cbranch_scc1 L_copy_%=\n\t"                                                                                     \
+    "v_cmp_gt_u32 vcc, %[npend], %[lane]\n\t"                                                                             \
+    "s_add_u32 %[e], %[opb], %[a0]\n\t"                                                                                \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    WR " %[va], %[lit]\n\t"                                                                                            \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_mov_b32 %[opb], %[op]\n\t"                                                                                      \
+    "s_mov_b32 %[npend], 0\n\t"                                                                                        \
+    "L_copy_%=:\n\t"                                                                                                   \
+    /* destination: ring slot of op + lane, lanes below len */                                                        \
+    "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"                                                                            \
+    "s_add_u32 %[e], %[op], %[a0]\n\t"                                                                                 \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_subrev_u32 %[vb], %[dist], %[va]\n\t"                                                                           \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_cmp_gt_u32 %[dist], %[op]\n\t"                                                                                  \
+    "s_cbranch_scc1 L_before_%=\n\t"                                                                                   \
+    "s_cmp_gt_u32 %[dist], %[near]\n\t"                                                                                \
+    "s_cbranch_scc1 L_far_%=\n\t"                                                                                      \
+    "s_cmp_lt_u32 %[dist], %[len]\n\t"                                                                                 \
+    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    /* source in the ring, no overlap */                                                                              \
+    "v_and_b32 %[vb], %[mask], %[vb]\n\t"                                                                              \
+    "v_lshl_add_u32 %[vb], %[vb], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    RD " %[vb], %[vb]\n\t"                                                                                             \
+    "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    /* source behind the ring's reach: it has been flushed (op - flushed < kFlushAt < kNear - 64), so it is in HBM,   \
+       and the flush had its stores acknowledged */                                                                   \
+    "L_far_%=:\n\t"                                                                                                    \
+    "s_sub_u32 %[t0], %[op], %[dist]\n\t"                                                                              \
+    "v_add_u32 %[vb], %[t0], %[lane]\n\t"                                                                              \
+    "v_lshlrev_b32 %[vb], %[sh], %[vb]\n\t"                                                                            \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vb], %[vb], %[outp]\n\t"                                                                                    \
+    "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                           \
+    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    "L_before_%=:\n\t"                                                                                                 \
+    BEFORE                                                                                                             \
+    "L_exit2_%=:\n\t"                                                                                                  \
+    "s_mov_b32 %[stage], 2\n\t"                                                                                        \
+    "s_branch L_end_%=\n\t"                                                                                            \
+    "L_exit1_%=:\n\t"                                                                                                  \
+    "s_mov_b32 %[stage], 1\n\t"                                                                                        \
+    "s_branch L_end_%=\n\t"                                                                                            \
+    "L_exit0_%=:\n\t"                                                                                                  \
+    "s_mov_b32 %[stage], 0\n\t"                                                                                        \
+    "L_end_%=:\n\t"
+
+// a source in front of `out`.  Whole streams: the dictionary -- the general code's business.  Parts: the bytes in front of
+// a part are not known yet, the copy writes their NAMES (symbol 256 + 32768 + position, position < 0); done here when the
+// whole copy lies in front (a copy that crosses into the part is left to the general code), after the reference's
+// "too far back" test and with the furthest reach noted.
+#define ZR_INFLATE_BEFORE_STREAM "s_branch L_exit2_%=\n\t"
+#define ZR_INFLATE_BEFORE_PART                                                                                         \
+    "s_add_u32 %[t1], %[op], %[dictlen]\n\t"                                                                           \
+    "s_cmp_gt_u32 %[dist], %[t1]\n\t"                                                                                  \
+    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    "s_sub_u32 %[t0], %[dist], %[op]\n\t"                                                                              \
+    "s_max_u32 %[reach], %[reach], %[t0]\n\t"                                                                          \
+    "s_cmp_gt_u32 %[len], %[t0]\n\t"                                                                                   \
+    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    "s_sub_u32 %[t1], 33024, %[t0]\n\t"                                                                                \
+    "v_add_u32 %[vb], %[t1], %[lane]\n\t"                                                                              \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    "ds_write_b16 %[va], %[vb]\n\t"                                                                                    \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
+    "s_branch L_top_%=\n\t"
+
 // PART = false: a job is a whole stream, the output is bytes (the many-stream entry points).
 // PART = true (inflate_large.hip): a job is a PART of one large stream -- the decode starts at bit starts[job] of the
 // stream, in the middle of it, and runs until a block ends exactly on a later entry of `starts` (or the stream ends).
@@ -207,10 +417,12 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     typedef typename std::conditional<PART, uint16_t, uint8_t>::type T;
     constexpr uint32_t E = 16u / (uint32_t)sizeof(T);   // elements per 16-byte store
     constexpr uint32_t M = RING - 1;
-    constexpr uint32_t kFlushAt = RING / 2;              // unflushed bytes that trigger a flush
+    constexpr uint32_t kFlushAt = RING >= 4096 ? RING / 2 : RING / 4;   // unflushed bytes that trigger a flush
+    constexpr uint32_t kStoredPiece = RING >= 4096 ? 1024u : RING / 4;  // a stored block enters the ring in pieces of this
     constexpr uint32_t kNear = RING - 258;               // a source this close is still in the ring while the match is written
-    // bytes not yet flushed never exceed kFlushAt + 16 + max(258, 1024); a match of 258 more must not overwrite them
-    static_assert(kFlushAt + 16 + 1024 + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
+    // bytes not yet flushed never exceed kFlushAt + 16 + max(258, kStoredPiece); a match of 258 more must not overwrite them
+    static_assert(kFlushAt + 16 + kStoredPiece + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
+    static_assert(kFlushAt + 64 < kNear, "a source beyond kNear must have left the ring (the fast loop reads it from HBM)");
     __shared__ InflateLds<RING, T> L;
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
@@ -272,6 +484,10 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
 
     uint32_t op = 0, flushed = 0;
     uint32_t msg = kMsgNone;
+#ifdef ZR_INFLATE_STATS
+    unsigned long long zr_tasm = 0;
+    const unsigned long long zr_tstart = __builtin_readcyclecounter();
+#endif
     // A run of literals waits in ONE vector register, literal j in lane j (a compare and a select per literal,
     // no LDS access, no EXEC juggling); the run goes to the ring in one ds_write when a match, a flush or the 64th
     // literal comes.  `op` already counts the waiting literals.
@@ -382,7 +598,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             if (n > out_cap - op) n = out_cap - op;
             for (uint32_t done_n = 0; done_n < n;) {
                 if (op - flushed >= kFlushAt) flush(op, false);
-                const uint32_t piece = n - done_n < 1024u ? n - done_n : 1024u;
+                const uint32_t piece = n - done_n < kStoredPiece ? n - done_n : kStoredPiece;
                 const uint32_t lo = 16u * (uint32_t)lane;
                 if (lo < piece) {
                     const ZR_GLOBAL uint8_t *src = in + from + done_n + lo;
@@ -480,70 +696,104 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         }
 
         // ---- symbol loop: the decode AND store halves of inflate_fast (inffast_tpl.h:140-300) -----------------------
+        // Each round: the hand-written fast loop (ZR_INFLATE_FAST_LOOP) runs until a symbol needs more than it does, then
+        // that ONE symbol is finished here, from the stage the fast loop left it in.
+        const uint32_t lds_lit = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)L.lit,
+                       lds_dist = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)L.dist,
+                       lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)L.ring;
         for (;;) {
-            // literals: the tight loop; it ends at the first symbol that is not a literal
-            uint32_t e;
-            for (;;) {
-                if (cnt < 32) append();
-                e = uni(L.lit[(uint32_t)hold & ((1u << kLitRoot) - 1u)]);
-                if (e >= (256u << 4)) break;
-                const uint32_t nb = e & 15u;
-                hold >>= nb;
-                cnt -= nb;
-                litbuf = (uint32_t)lane == npend ? (e >> 4) : litbuf;
-                ++npend;
-                ++op;
-                if (npend == 64) {
-                    service();
-                    if (msg != kMsgNone) break;
-                }
+            if (npend == 64) {
+                service();
+                if (msg != kMsgNone) break;
             }
-            if (msg != kMsgNone) break;
-            if (e == kLongMark) {
-                e = long_code(L, kCodeLit, kLitRoot, L.sorted_lit, hold);
-                if (e < (256u << 4)) {                                                // a literal with a long code
+            uint32_t stage, len = 0, dist = 0;
+            {
+                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, ee, opx, va, vb;
+                // no flush is due and the match fits `out` while op + len <= oplim (what service() would test)
+                const uint32_t fl = flushed + kFlushAt - 1u, oplim = out_cap < fl ? out_cap : fl;
+                const unsigned long long out_addr = (unsigned long long)(uintptr_t)J.out;
+#ifdef ZR_INFLATE_STATS
+                const unsigned long long zr_t0 = __builtin_readcyclecounter();
+#endif
+                if constexpr (sizeof(T) == 1) {
+                    asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u8", "ds_write_b8", "global_load_ubyte", ZR_INFLATE_BEFORE_STREAM)
+                                 : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
+                                   [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb)
+                                 : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
+                                   [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(0),
+                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
+                                 : "scc", "vcc", "memory", "s42", "s43", "s44", "s45");
+                } else {
+                    asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u16", "ds_write_b16", "global_load_ushort", ZR_INFLATE_BEFORE_PART)
+                                 : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
+                                   [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb)
+                                 : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
+                                   [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(1),
+                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
+                                 : "scc", "vcc", "memory", "s42", "s43", "s44", "s45");
+                }
+#ifdef ZR_INFLATE_STATS
+                zr_tasm += __builtin_readcyclecounter() - zr_t0;
+#endif
+                wnext = cbase + widx;
+                if (widx == 64) {                                                     // the 64 fetched words are used up
+                    cbase += 64;
+                    cur = nxt;
+                    nxt = fetch(cbase + 64);
+                }
+                op = opb + npend;
+                ZR_STAT(0);
+                if (stage == 0) ZR_STAT(npend == 64 ? 1 : widx == 64 ? 2 : 3);          // 64 literals wait / the fetched words are used up / EOB, long or bad code
+                if (stage == 1) ZR_STAT(widx == 64 ? 4 : 5);                          // words used up / long or bad distance code
+                if (stage == 2) ZR_STAT(len > 64 ? 6 : op + len > oplim ? 7 : dist > op ? 8 : dist < len ? 9 : 10);
+                if (stage == 0 && npend == 64) continue;
+            }
+            if (stage == 0) {
+                if (cnt < 32) append();
+                uint32_t e = uni(L.lit[(uint32_t)hold & ((1u << kLitRoot) - 1u)]);
+                if (e == kLongMark) e = long_code(L, kCodeLit, kLitRoot, L.sorted_lit, hold);
+                if (e < (256u << 4)) {                                                // a literal (here: one with a long code)
                     const uint32_t nb = e & 15u;
                     hold >>= nb;
                     cnt -= nb;
                     litbuf = (uint32_t)lane == npend ? (e >> 4) : litbuf;
                     ++npend;
                     ++op;
-                    if (npend == 64) {
-                        service();
-                        if (msg != kMsgNone) break;
-                    }
                     continue;
                 }
+                const uint32_t sym = e >> 4, nb = e & 15u;
+                if (sym > 285u) { msg = kMsgLitLenCode; break; }                      // 286, 287 (inftrees.c:44-45), no code
+                hold >>= nb;
+                cnt -= nb;
+                if (sym == 256u) break;                                               // end of block
+                // length: base and extra bits from the symbol (RFC 1951 3.2.5; inftrees.c:38-45 tabulate the same)
+                const uint32_t k = sym - 257u;
+                if (k < 8u) {
+                    len = 3u + k;
+                } else if (k == 28u) {
+                    len = 258u;
+                } else {
+                    const uint32_t xb = (k - 4u) >> 2;
+                    len = 3u + ((4u + (k & 3u)) << xb) + ((uint32_t)hold & ((1u << xb) - 1u));
+                    hold >>= xb;
+                    cnt -= xb;
+                }
             }
-            const uint32_t sym = e >> 4, nb = e & 15u;
-            if (sym > 285u) { msg = kMsgLitLenCode; break; }                          // 286, 287 (inftrees.c:44-45), no code
-            hold >>= nb;
-            cnt -= nb;
-            if (sym == 256u) break;                                                   // end of block
-            // length: base and extra bits from the symbol (RFC 1951 3.2.5; inftrees.c:38-45 tabulate the same)
-            const uint32_t k = sym - 257u;
-            uint32_t len;
-            if (k < 8u) {
-                len = 3u + k;
-            } else if (k == 28u) {
-                len = 258u;
-            } else {
-                const uint32_t xb = (k - 4u) >> 2;
-                len = 3u + ((4u + (k & 3u)) << xb) + ((uint32_t)hold & ((1u << xb) - 1u));
-                hold >>= xb;
-                cnt -= xb;
+            if (stage <= 1) {
+                if (cnt < 32) append();
+                uint32_t d = uni(L.dist[(uint32_t)hold & ((1u << kDistRoot) - 1u)]);
+                if (d >= kBadWide) {
+                    if (d == kLongWide) d = wide_distance(long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold));
+                    if (d >= kBadWide) { msg = kMsgDistCode; break; }
+                }
+                const uint32_t dnb = d & 15u, dxb = (d >> 4) & 15u;
+                hold >>= dnb;
+                dist = (d >> 8) + ((uint32_t)hold & ((1u << dxb) - 1u));
+                hold >>= dxb;
+                cnt -= dnb + dxb;
             }
-            if (cnt < 32) append();
-            uint32_t d = uni(L.dist[(uint32_t)hold & ((1u << kDistRoot) - 1u)]);
-            if (d >= kBadWide) {
-                if (d == kLongWide) d = wide_distance(long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold));
-                if (d >= kBadWide) { msg = kMsgDistCode; break; }
-            }
-            const uint32_t dnb = d & 15u, dxb = (d >> 4) & 15u;
-            hold >>= dnb;
-            const uint32_t dist = (d >> 8) + ((uint32_t)hold & ((1u << dxb) - 1u));
-            hold >>= dxb;
-            cnt -= dnb + dxb;
             if (dist > op + dict_len) { msg = kMsgTooFar; break; }                    // inffast_tpl.h:203-210
             if (PART && dist > op && dist - op > reach) reach = dist - op;
             service();
@@ -599,6 +849,17 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         }
         if (PART && !last && msg == kMsgNone && block_end_stop()) break;
     }
+#ifdef ZR_INFLATE_STATS
+    if (lane == 0) {
+        const unsigned long long zr_tend = __builtin_readcyclecounter();
+        atomicAdd(&g_inflate_stats[11], zr_tasm);
+        atomicAdd(&g_inflate_stats[12], zr_tend - zr_tstart);
+        if (job < 16384u) {
+            g_inflate_span[2 * job] = zr_tstart;
+            g_inflate_span[2 * job + 1] = zr_tend;
+        }
+    }
+#endif
     // bits that do not exist were consumed: whatever happened after that point, the stream ended early
     if (msg != kMsgOutFull) service();                   // (an out-of-room exit has clipped the run already)
     // (a part keeps its out-of-room exit: inflate_large.hip gives it a larger slot and runs it again)
@@ -663,6 +924,18 @@ using namespace zr;
 
 extern "C" {
 
+#ifdef ZR_INFLATE_STATS
+void zng_rocm_debug_inflate_spans(unsigned long long *out, unsigned n) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(zr::g_inflate_span), (size_t)(n < 16384u ? n : 16384u) * 16);
+}
+void zng_rocm_debug_inflate_stats(unsigned long long *out16, int reset) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(zr::g_inflate_stats), 16 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(zr::g_inflate_stats), z, sizeof z);
+    }
+}
+#endif
 #ifdef ZR_INFLATE_BOUNDS
 unsigned int zng_rocm_debug_inflate_bounds(void) {
     unsigned int v = 0;

@@ -8,7 +8,8 @@
 //        would accept, cheap tests first: BTYPE / HLIT / HDIST in range (inflate.c:808-813), the code-length code complete
 //        (inftrees.c:126-131; a Kraft sum over the 3-bit fields, three fields per table lookup).  About 1 position in
 //        10^3 is left.  Also: the byte pattern 00 00 ff ff of a sync-flush marker (deflate.c:1064-1076) -- the block
-//        behind it starts on the next byte, whatever its type.
+//        behind it starts on the next byte, whatever its type -- and a stored block's header on a byte boundary
+//        (header byte, LEN, NLEN = ~LEN; inflate.c:759-775): incompressible data is a chain of those.
 //   F2 validate_headers_kernel  one lane per survivor decodes the whole header (inflate.c:814-917) and applies the
 //        validity rules of inflate_table to the two code sets (inftrees.c:104-137): about 1 random position in 10^6
 //        survives both kernels, real block starts all do.
@@ -113,6 +114,17 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
                 const uint32_t i = atomicAdd(&nlocal, 1u);
                 if (i < kFindLocal) local[i] = (8ull * (b + 4)) | (1ull << 63);
             }
+            // a stored block that starts on a byte boundary (as every stored block behind another one does: a run of
+            // incompressible data is a chain of them, and without these starts it would be ONE part -- 8 MiB of the cfg3 mix
+            // were, and that part was the whole kernel's tail): header byte 0 or 1, LEN, NLEN = ~LEN.  Noise passes this
+            // once in 2^23 bytes; a false start costs one wasted part (nothing ever ends on it).
+            {
+                const uint32_t len16 = (uint32_t)(lo >> 8) & 0xffffu, nlen16 = (uint32_t)(lo >> 24) & 0xffffu;
+                if (((uint32_t)lo & 0xfeu) == 0u && len16 != 0u && (len16 ^ nlen16) == 0xffffu && b + 5 + len16 <= src_len) {
+                    const uint32_t i = atomicAdd(&nlocal, 1u);
+                    if (i < kFindLocal) local[i] = (8ull * b) | (1ull << 63);
+                }
+            }
 #pragma unroll
             for (unsigned k = 0; k < 8; ++k) {
                 const unsigned long long v = k ? (lo >> k) | (hi << (64 - k)) : lo;
@@ -139,23 +151,30 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
 }
 
 // F2.  One lane per survivor of F1: the whole dynamic header (inflate.c:814-917) and inflate_table's validity rules for the
-// literal/length and the distance code (inftrees.c:104-137).  Per lane in LDS: the code-length code as a 128-entry direct
-// table (length << 5 | symbol) and the 316 code lengths.  valid[i] = 1 / 0.
+// literal/length and the distance code (inftrees.c:104-137).  Those rules are statements about Kraft sums, so the code
+// lengths are summed as they are decoded and never stored: a set is over-subscribed when its sum passes 1 (the lane
+// leaves at once -- noise does so within a few symbols, which is what keeps this kernel short), complete when it ends at
+// exactly 1, and an incomplete set is allowed only as ONE code of length 1 (inftrees.c:133-134: left > 0 needs max == 1).
+// Per lane in LDS: the code-length code as a 128-entry direct table (length << 5 | symbol).  Survivors are appended to
+// good[] (bit positions; the marker bit removed).
 constexpr int kValLanes = 64;
 __global__ __launch_bounds__(kValLanes)
 void validate_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src_len,
-                             const unsigned long long *__restrict__ cand, uint32_t n, uint8_t *__restrict__ valid) {
+                             const unsigned long long *__restrict__ cand, uint32_t n, unsigned long long *__restrict__ good,
+                             uint32_t *__restrict__ ngood, uint32_t cap) {
     __shared__ uint8_t tab[kValLanes][128];
-    __shared__ uint8_t lens[kValLanes][320];
     const uint32_t i = blockIdx.x * kValLanes + threadIdx.x;
     if (i >= n) return;
     const unsigned long long c0 = cand[i];
+    auto accept = [&]() {
+        const uint32_t at = atomicAdd(ngood, 1u);
+        if (at < cap) good[at] = c0 & ~(1ull << 63);
+    };
     if (c0 >> 63) {                                       // behind a marker: taken as it is
-        valid[i] = 1;
+        accept();
         return;
     }
-    valid[i] = 0;
-    uint8_t *T = tab[threadIdx.x], *Ln = lens[threadIdx.x];
+    uint8_t *T = tab[threadIdx.x];
     const unsigned long long bit = c0;
     unsigned long long w = bits_at_dev(src, src_len, bit + 3);
     const unsigned nlen = (unsigned)(w & 31) + 257, ndist = (unsigned)((w >> 5) & 31) + 1, ncode = (unsigned)((w >> 10) & 15) + 4;
@@ -205,62 +224,68 @@ void validate_headers_kernel(const uint8_t *__restrict__ src, unsigned long long
         const unsigned rev = __builtin_bitreverse32(code) >> (32 - l);
         for (unsigned e = rev; e < 128; e += 1u << l) T[e] = (uint8_t)((l << 5) | (unsigned)s);
     }
-    unsigned have = 0;
+    // Kraft sums in 1/32768; codes used and the longest code per set; the length the end-of-block symbol got
+    unsigned have = 0, prev = 0, eob = 0;
+    unsigned kraft[2] = {0, 0}, used[2] = {0, 0}, longest[2] = {0, 0};
     const unsigned total = nlen + ndist;
+    // `rep` symbols from `have` on get code length l.  No loop over the run: the lanes of a wave execute the longest run
+    // any of them has (138 zeros is common), and that loop was most of this kernel's time.
+    auto put = [&](unsigned l, unsigned rep) -> bool {
+        if (have <= 256u && 256u < have + rep) eob = l;
+        if (l) {
+            const unsigned n0 = have < nlen ? (rep < nlen - have ? rep : nlen - have) : 0u, n1 = rep - n0;
+            kraft[0] += n0 * (32768u >> l);
+            kraft[1] += n1 * (32768u >> l);
+            used[0] += n0;
+            used[1] += n1;
+            if (n0 && l > longest[0]) longest[0] = l;
+            if (n1 && l > longest[1]) longest[1] = l;
+        }
+        have += rep;
+        return kraft[0] <= 32768u && kraft[1] <= 32768u;
+    };
+    unsigned long long hold = bits_at_dev(src, src_len, pos);
+    unsigned spent = 0;                                   // bits of `hold` used up
     while (have < total) {
-        const unsigned long long v = bits_at_dev(src, src_len, pos);
+        if (spent > 48u) {                                // a symbol takes at most 7 + 7 bits
+            pos += spent;
+            if ((pos >> 3) + 8 > src_len) return;
+            hold = bits_at_dev(src, src_len, pos);
+            spent = 0;
+        }
+        const unsigned long long v = hold >> spent;
         const unsigned e = T[(unsigned)v & 127u];
         const unsigned nb = e >> 5, sym = e & 31u;
-        pos += nb;
+        spent += nb;
         if (sym < 16) {
-            Ln[have++] = (uint8_t)sym;
+            prev = sym;
+            if (!put(sym, 1)) return;
             continue;
         }
         unsigned rep, val = 0;
         const unsigned long long x = v >> nb;
         if (sym == 16) {
             if (have == 0) return;
-            val = Ln[have - 1];
+            val = prev;
             rep = 3 + (unsigned)(x & 3);
-            pos += 2;
+            spent += 2;
         } else if (sym == 17) {
             rep = 3 + (unsigned)(x & 7);
-            pos += 3;
+            spent += 3;
         } else {
             rep = 11 + (unsigned)(x & 127);
-            pos += 7;
+            spent += 7;
         }
         if (have + rep > total) return;
-        while (rep--) Ln[have++] = (uint8_t)val;
-        if ((pos >> 3) + 8 > src_len) return;
+        prev = val;
+        if (!put(val, rep)) return;
     }
-    if (Ln[256] == 0) return;                             // no end-of-block code (inflate.c:897-901)
-    // inflate_table's checks on both sets: not over-subscribed; incomplete only with a single code of length 1
-    for (int set = 0; set < 2; ++set) {
-        const unsigned from = set ? nlen : 0, cnt = set ? ndist : nlen;
-        unsigned c16[16];
-#pragma unroll
-        for (int l = 0; l < 16; ++l) c16[l] = 0;
-        for (unsigned s = 0; s < cnt; ++s) {
-            const unsigned l = Ln[from + s];
-#pragma unroll
-            for (int q = 1; q < 16; ++q)
-                if (l == (unsigned)q) ++c16[q];
-        }
-        int left = 1, max = 0;
-#pragma unroll
-        for (int l = 1; l < 16; ++l) {
-            left = (left << 1) - (int)c16[l];
-            if (left < 0) return;
-            if (c16[l]) max = l;
-        }
-        if (max == 0) {
-            if (set == 0) return;                         // no literal/length code at all
-            continue;                                     // no distance codes: allowed (inftrees.c:114-122)
-        }
-        if (left > 0 && max != 1) return;
-    }
-    valid[i] = 1;
+    if ((((pos + spent) >> 3) + 8) > src_len) return;
+    if (eob == 0) return;                                 // no end-of-block code (inflate.c:897-901)
+    // literal/length set: complete, or the single code of length 1; distance set: the same, or no code at all
+    if (kraft[0] != 32768u && !(used[0] == 1u && longest[0] == 1u)) return;
+    if (kraft[1] != 32768u && !(used[1] == 0u || (used[1] == 1u && longest[1] == 1u))) return;
+    accept();
 }
 
 struct PartCopy {
@@ -329,6 +354,10 @@ int inflate_resolve_symbols(const uint64_t *d_segs, size_t nsegs, uint16_t *sym,
                             uint32_t window_len, hipStream_t st);
 
 static thread_local int t_large_parts = 0;
+#ifdef ZR_INFLATE_STATS
+static std::vector<unsigned long long> g_dbg_starts;     // diagnostic builds: the last call's part starts and result words
+static std::vector<uint32_t> g_dbg_res;
+#endif
 
 // why the device path handed the stream to the sequential decoder (readable through zng_rocm_last_error())
 static int why(const char *reason) {
@@ -342,12 +371,12 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     if (src_len < (128u << 10) || src_len >= (1ull << 31)) return why("stream below 128 KiB (or 2 GiB and more)");
     // ---- candidates ---------------------------------------------------------------------------------------------
     const uint32_t cap1 = (uint32_t)std::min<size_t>(src_len / 64 + 4096, 64u << 20);
+    const uint32_t cap2 = (uint32_t)std::min<size_t>(src_len / 512 + 4096, 8u << 20);      // starts are >= 2 KiB apart in the end
     uint8_t *fp = nullptr;
-    if (int rc = scratch_reserve(ws, kScrLargeCand, (size_t)cap1 * 9 + 64, false, (void **)&fp)) return rc;
-    unsigned long long *d_cand = (unsigned long long *)fp;
-    uint8_t *d_valid = fp + (size_t)cap1 * 8;
-    uint32_t *d_n = (uint32_t *)(d_valid + (((size_t)cap1 + 15) & ~(size_t)15));
-    ZR_HIP(hipMemsetAsync(d_n, 0, 4, st));
+    if (int rc = scratch_reserve(ws, kScrLargeCand, ((size_t)cap1 + cap2) * 8 + 64, false, (void **)&fp)) return rc;
+    unsigned long long *d_cand = (unsigned long long *)fp, *d_good = d_cand + cap1;
+    uint32_t *d_n = (uint32_t *)(d_good + cap2);          // [0] survivors of F1, [1] of F2
+    ZR_HIP(hipMemsetAsync(d_n, 0, 8, st));
     hipLaunchKernelGGL(find_headers_kernel, dim3(4096), dim3(256), 0, st, d_src, (unsigned long long)src_len, d_cand, d_n, cap1);
     ZR_HIP(hipGetLastError());
     uint32_t n1 = 0;
@@ -355,17 +384,17 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     ZR_HIP(hipStreamSynchronize(st));
     if (n1 == 0 || n1 > cap1) return why("no candidate block starts, or far more than a deflate stream has");
     hipLaunchKernelGGL(validate_headers_kernel, dim3((n1 + kValLanes - 1) / kValLanes), dim3(kValLanes), 0, st, d_src,
-                       (unsigned long long)src_len, d_cand, n1, d_valid);
+                       (unsigned long long)src_len, d_cand, n1, d_good, d_n + 1, cap2);
     ZR_HIP(hipGetLastError());
-    std::vector<unsigned long long> cand(n1);
-    std::vector<uint8_t> valid(n1);
-    ZR_HIP(hipMemcpyAsync(cand.data(), d_cand, (size_t)n1 * 8, hipMemcpyDeviceToHost, st));
-    ZR_HIP(hipMemcpyAsync(valid.data(), d_valid, n1, hipMemcpyDeviceToHost, st));
+    uint32_t n2 = 0;
+    ZR_HIP(hipMemcpyAsync(&n2, d_n + 1, 4, hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> good;
-    good.reserve(n1);
-    for (uint32_t i = 0; i < n1; ++i)
-        if (valid[i]) good.push_back(cand[i] & ~(1ull << 63));
+    if (n2 > cap2) return why("far more valid block headers than a deflate stream has");
+    std::vector<unsigned long long> good(n2);
+    if (n2) {
+        ZR_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+        ZR_HIP(hipStreamSynchronize(st));
+    }
     std::sort(good.begin(), good.end());
     std::vector<unsigned long long> starts;
     starts.push_back(0);
@@ -435,6 +464,10 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
         }
     }
 
+#ifdef ZR_INFLATE_STATS
+    g_dbg_starts = starts;
+    g_dbg_res = res;
+#endif
     // ---- the chain from bit 0 -------------------------------------------------------------------------------------
     std::vector<PartCopy> copies;
     uint64_t produced = 0;
@@ -517,6 +550,16 @@ using namespace zr;
 extern "C" {
 
 int zng_rocm_inflate_large_last_parts(void) { return t_large_parts; }
+#ifdef ZR_INFLATE_STATS
+unsigned zng_rocm_debug_large_parts(unsigned long long *starts, uint32_t *res8, unsigned cap) {
+    const unsigned n = (unsigned)std::min<size_t>(cap, g_dbg_starts.size());
+    for (unsigned i = 0; i < n; ++i) {
+        starts[i] = g_dbg_starts[i];
+        for (int k = 0; k < 8; ++k) res8[8 * i + k] = g_dbg_res[8 * (size_t)i + k];
+    }
+    return (unsigned)g_dbg_starts.size();
+}
+#endif
 
 int zng_rocm_inflate_large_dev(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream) {
