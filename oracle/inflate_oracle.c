@@ -115,6 +115,18 @@ static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 
 static const uint16_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
                                         7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
+/* test aid: where the blocks of the next oracle_inflate_raw* call start (bit position of BFINAL) and their BTYPE */
+static uint64_t *trace_bits;
+static uint8_t *trace_types;
+static size_t trace_cap, trace_n;
+void oracle_inflate_trace_blocks(uint64_t *bits, uint8_t *types, size_t cap) {
+    trace_bits = bits;
+    trace_types = types;
+    trace_cap = cap;
+    trace_n = 0;
+}
+size_t oracle_inflate_traced_blocks(void) { return trace_n; }
+
 #define FAIL(m) do { res->status = ORACLE_Z_DATA_ERROR; res->msg = (m); goto done; } while (0)
 #define STARVED() do { res->status = ORACLE_Z_BUF_ERROR; res->msg = "input ended before the final block"; goto done; } while (0)
 
@@ -132,9 +144,17 @@ static int inflate_core(const uint8_t *src, size_t src_len, uint8_t *dst, size_t
     res->status = ORACLE_Z_OK;
     res->msg = "";
     do {
+        const uint64_t block_bit = 8ull * br.in_pos - (uint64_t)br.bitcnt;
         last = getbits(&br, 1);
         int type = getbits(&br, 2);
         if (br.starved) STARVED();
+        if (trace_bits) {
+            if (trace_n < trace_cap) {
+                trace_bits[trace_n] = block_bit;
+                trace_types[trace_n] = (uint8_t)type;
+            }
+            trace_n++;
+        }
         if (type == 3) FAIL("invalid block type");
         if (type == 0) {
             br.bitbuf = 0;                              /* BYTEBITS, inflate.c:761 */

@@ -105,6 +105,10 @@ typedef struct oracle_inflate_result {
 
 int oracle_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap,
                        oracle_inflate_result *res);
+/* test aid: record the bit position (of BFINAL) and BTYPE of every block the next oracle_inflate_raw* call walks
+ * (at most cap; pass NULL to switch off); oracle_inflate_traced_blocks() = how many there were */
+void oracle_inflate_trace_blocks(uint64_t *bits, uint8_t *types, size_t cap);
+size_t oracle_inflate_traced_blocks(void);
 /* the same after inflateSetDictionary (inflate.c:1214-1261) */
 int oracle_inflate_raw_dict(const uint8_t *src, size_t src_len, const uint8_t *dict, size_t dict_len,
                             uint8_t *dst, size_t dst_cap, oracle_inflate_result *res);

@@ -32,3 +32,20 @@ def oracle_inflate_dict(src, dictionary, cap):
     res = _Res()
     fn(C.addressof(sbuf), len(src), C.addressof(kbuf), len(dictionary), C.addressof(dbuf), cap, C.byref(res))
     return res.status, (res.msg or b"").decode(), dbuf.raw[:res.out_len], res.in_used
+
+
+def oracle_block_starts(src, cap):
+    """(bit position of BFINAL, BTYPE) of every block of a raw deflate stream, as the oracle walks it"""
+    lib = oracle_lib.load()
+    lib.oracle_inflate_trace_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.oracle_inflate_traced_blocks.restype = C.c_size_t
+    n_max = 1 << 20
+    bits = (C.c_uint64 * n_max)()
+    types = (C.c_uint8 * n_max)()
+    lib.oracle_inflate_trace_blocks(bits, types, n_max)
+    try:
+        status = oracle_inflate(src, cap)[0]
+        n = min(n_max, lib.oracle_inflate_traced_blocks())
+    finally:
+        lib.oracle_inflate_trace_blocks(None, None, 0)
+    return status, [(int(bits[i]), int(types[i])) for i in range(n)]

@@ -42,6 +42,23 @@ def test_cpython_streams_are_cut_and_decoded_on_the_device(mods, level, mib):
     assert int(dst[n:].max()) == 0                        # nothing written behind the end
 
 
+def test_nearly_every_block_start_becomes_a_part(mods):
+    """the finder's completeness, through the public part count: a CPython level-6 stream of the mix has dynamic blocks
+    (among them headers with all 19 code-length fields, which a mask bug once hid) and chains of stored blocks"""
+    import inflate_util
+    torch, inf, _ = mods
+    plain = synth.silesia_like(48 << 20, seed=0x5EED0003)
+    comp = _raw(plain.tobytes(), 6)
+    status, blocks = inflate_util.oracle_block_starts(comp, plain.size)
+    assert status == 1 and len(blocks) > 400
+    src = torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()
+    dst = torch.zeros(plain.size, dtype=torch.uint8, device="cuda")
+    st, n, used, parts = inf.inflate_large_dev(src, dst)
+    assert (st, n, used) == (1, plain.size, len(comp))
+    assert parts >= 0.97 * len(blocks), (parts, len(blocks))
+    assert torch.equal(dst.cpu(), torch.from_numpy(plain))
+
+
 def test_own_level6_stream_with_sync_markers(mods):
     torch, inf, dfl = mods
     plain = synth.silesia_like(48 << 20, seed=77)

@@ -34,25 +34,20 @@ if os.environ.get("ZR_STATS_LIB"):
     import ctypes as C
     L = zr.rocm.lib(); st = (C.c_ulonglong * 16)()
     L.zng_rocm_debug_inflate_stats(st, 1); inf.inflate_large_dev(src, dst); torch.cuda.synchronize(); L.zng_rocm_debug_inflate_stats(st, 0)
-    names = ["loop entries", "0: 64 literals wait", "0: fetched words used up", "0: EOB / long / bad code", "1: words used up",
-             "1: long / bad distance code", "2: len > 64", "2: flush or end of out due", "2: source in front of out", "2: overlap (dist < len)", "2: other"]
-    print("per part:", ", ".join("%s %.0f" % (n, st[i] / parts) for i, n in enumerate(names)))
-    print("s_memtime ticks per part: inside the hand-written loop %.0f, whole decode %.0f" % (st[11] / parts, st[12] / parts))
-    sp = (C.c_ulonglong * (2 * parts))(); L.zng_rocm_debug_inflate_spans(sp, parts)
-    a = np.array(sp, dtype=np.uint64).reshape(-1, 2).astype(np.int64); t0 = a[:, 0].min()
-    dur = (a[:, 1] - a[:, 0]); st_ = a[:, 0] - t0; en = a[:, 1] - t0
-    q = np.percentile(dur, [0, 10, 50, 90, 99, 100])
-    print("part durations (Mticks): min %.2f p10 %.2f median %.2f p90 %.2f p99 %.2f max %.2f; sum %.0f" % (*(q / 1e6), dur.sum() / 1e6))
-    print("starts (Mticks): median %.2f p90 %.2f max %.2f; last end %.2f" % (np.median(st_) / 1e6, np.percentile(st_, 90) / 1e6, st_.max() / 1e6, en.max() / 1e6))
-    late = st_ > 0.05 * en.max()
-    print("parts that started late (after 5%% of the kernel): %d, their median duration %.2f Mticks" % (late.sum(), np.median(dur[late]) / 1e6 if late.any() else 0))
-    cap = 1 << 16
+    cap = 1 << 14
     stt = (C.c_ulonglong * cap)(); rs = (C.c_uint32 * (8 * cap))(); L.zng_rocm_debug_large_parts.restype = C.c_uint
-    npart = L.zng_rocm_debug_large_parts(stt, rs, cap)
+    npart = min(cap, L.zng_rocm_debug_large_parts(stt, rs, cap))
     stt = np.array(stt[:npart], dtype=np.uint64).astype(np.int64); rs = np.array(rs[:8 * npart], dtype=np.uint32).reshape(-1, 8)
+    sp = (C.c_ulonglong * (2 * npart))(); L.zng_rocm_debug_inflate_spans(sp, npart)
+    a = np.array(sp, dtype=np.uint64).reshape(-1, 2).astype(np.int64)
+    dur = a[:, 1] - a[:, 0]
+    q = np.percentile(dur, [0, 10, 50, 90, 99, 100])
+    print("%d part starts, %d on the chain; s_memtime ticks per part: inside the hand-written loop %.0f, whole decode %.0f"
+          % (npart, parts, st[11] / npart, st[12] / npart))
+    print("part durations (Mticks): min %.2f p10 %.2f median %.2f p90 %.2f p99 %.2f max %.2f; sum %.0f" % (*(q / 1e6), dur.sum() / 1e6))
     nbits = np.diff(np.append(stt, src.numel() * 8))
-    order = np.argsort(-dur[:npart])
-    print("slowest parts: index, Mticks, symbols produced, compressed bytes, ticks per symbol")
+    order = np.argsort(-dur)
+    print("slowest parts: index, Mticks, symbols produced, compressed bytes to the next start, ticks per symbol, message")
     for j in order[:8]:
-        print("  %5d %7.2f %8d %8d %7.0f" % (j, dur[j] / 1e6, rs[j, 0], nbits[j] // 8, dur[j] / max(1, rs[j, 0])))
-    print("median part: %d symbols, %d compressed bytes, %.0f ticks per symbol" % (np.median(rs[:, 0]), np.median(nbits) // 8, np.median(dur[:npart] / np.maximum(1, rs[:, 0]))))
+        print("  %5d %7.2f %8d %8d %7.0f %d" % (j, dur[j] / 1e6, rs[j, 0], nbits[j] // 8, dur[j] / max(1, rs[j, 0]), rs[j, 4]))
+    print("median part: %d symbols, %d compressed bytes, %.0f ticks per symbol" % (np.median(rs[:, 0]), np.median(nbits) // 8, np.median(dur / np.maximum(1, rs[:, 0]))))

@@ -36,7 +36,11 @@
 
 namespace zr {
 
-constexpr uint32_t kSpacingBytes = 2u << 10;      // least compressed bytes between two starts
+constexpr uint32_t kSpacingBytes = 2u << 10;      // least compressed bytes between two starts -- applied only when there are
+constexpr uint32_t kPartsUnthinned = 12288;       // more candidates than this.  (Thinning a short list loses real starts:
+                                                  // about one random bit position in 10^6 passes F1 + F2, and a false start
+                                                  // within the spacing in front of a real one would take its place; a false
+                                                  // start that is kept costs one wasted part and nothing else.)
 constexpr uint32_t kSegmentBytes = 40u << 10;     // parts are grouped into segments of at least this much OUTPUT for the
                                                   // context chain (which looks one segment back: >= 32 KiB each)
 constexpr uint32_t kSlotRatio = 64;               // symbols of slot per compressed byte of the part ...
@@ -132,7 +136,7 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
                 if (((h >> 1) & 3u) != 2u || ((h >> 3) & 31u) > 29u || ((h >> 8) & 31u) > 29u) continue;
                 const unsigned ncode = ((uint32_t)(v >> 13) & 15u) + 4u;
                 unsigned long long c = (lo >> (k + 17)) | (hi << (64 - (k + 17)));       // 57 bits: all 19 fields
-                if (ncode < 19) c &= (1ull << (3 * ncode)) - 1ull;
+                c &= (1ull << (3 * ncode)) - 1ull;                                          // (19 fields are 57 bits: the table lookups below read 63)
                 unsigned sum = 0;
 #pragma unroll
                 for (int g = 0; g < 7; ++g) sum += kraft9[(uint32_t)(c >> (9 * g)) & 511u];
@@ -398,8 +402,9 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     std::sort(good.begin(), good.end());
     std::vector<unsigned long long> starts;
     starts.push_back(0);
+    const unsigned long long spacing = good.size() > kPartsUnthinned ? 8ull * kSpacingBytes : 1ull;
     for (unsigned long long b : good)
-        if (b >= starts.back() + 8ull * kSpacingBytes && (b >> 3) + 16 < src_len) starts.push_back(b);
+        if (b >= starts.back() + spacing && (b >> 3) + 16 < src_len) starts.push_back(b);
     const size_t np = starts.size();
     if (np < 4) return why("fewer than four block starts found");
 
