@@ -307,6 +307,30 @@ def main():
                                         "bit_exact": bool(rc_t == 1 and produced_t == n and torch.equal(dst[:n], torch.from_numpy(plain).cuda()))}
         report["cfg3"]["one_stream_decode_on_T_threads"] = single
         del dst
+        # the same ONE stream, resident in HBM, decoded on the device alone (zng_rocm_inflate_large_dev): the
+        # CPython stream above, and this library's own level-6 stream of the same plaintext
+        d_plain = torch.from_numpy(plain).cuda()
+        own, own_len = dfl.deflate_dev(d_plain, level=6)
+        on_dev = {}
+        for name, d_comp in (("cpython_level6_stream", torch.from_numpy(np.frombuffer(comp, dtype=np.uint8).copy()).cuda()),
+                             ("own_level6_stream", own[:own_len].contiguous())):
+            dst = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            inf.inflate_large_dev(d_comp, dst)                                    # warm: scratch
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                st_l, n_l, used_l, parts_l = inf.inflate_large_dev(d_comp, dst)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            med = statistics.median(ts)
+            on_dev[name] = {"ms": round(med * 1e3, 2), "ms_range": [round(min(ts) * 1e3, 2), round(max(ts) * 1e3, 2)],
+                            "out_GBps": round(n / 1e9 / med, 2), "in_GBps": round(d_comp.numel() / 1e9 / med, 2),
+                            "parts": parts_l, "host_threads": 1,
+                            "bit_exact": bool(st_l == 1 and n_l == n and used_l == d_comp.numel() and torch.equal(dst, d_plain))}
+            del dst, d_comp
+        report["cfg3"]["one_stream_on_the_device"] = on_dev
+        del d_plain, own
         # many independent streams (the pigz shape): the same 256 MiB as 64 streams of 4 MiB, each compressed by the
         # device's own level-6 class (validated in cfg4), decoded on T host threads, resolved per stream on the device
         each = n // 64
