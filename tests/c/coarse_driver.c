@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "zng_rocm.h"
 #include "zlibng_coarse_min.h"
 #include "rocm_functions.h"
 #include "rocm_deflate.h"
@@ -265,5 +266,7 @@ int main(int argc, char **argv) {
     if (!fo || fwrite(out, 1, produced, fo) != produced) return 9;
     fclose(fo);
     printf("device %zu %zu\n", n, produced);
+    if (getenv("COARSE_DRIVER_PARTS"))              /* how many parts the device decoded the last member in (0: host decoder) */
+        printf("parts %d\n", zng_rocm_inflate_large_last_parts());
     return 0;
 }

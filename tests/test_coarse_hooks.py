@@ -37,8 +37,9 @@ def driver(tmp_path_factory):
     return exe
 
 
-def _run(exe, *args):
-    p = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+def _run(exe, *args, env=None):
+    p = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env) if env else None)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     return p.stdout.strip()
 
@@ -92,6 +93,34 @@ def test_inflate_hook_trickled_input(driver, tmp_path, wrap, in_chunk, out_chunk
     line = _run(driver, "i", wrap, in_chunk, out_chunk, tmp_path / "in.z", tmp_path / "out.bin", len(plain))
     assert line == "device %d %d" % (len(comp), len(plain)), line
     assert (tmp_path / "out.bin").read_bytes() == plain
+
+
+@pytest.mark.gpu
+def test_inflate_hook_decodes_a_large_member_on_the_device(driver, tmp_path):
+    """a member of more than 4 MiB of compressed bytes goes through inflate_large.hip (block starts found on the device,
+    one wavefront per part), with the history and the check value kept by the hook as before; a damaged one falls to the
+    sequential decoder and reports what the reference would"""
+    plain = synth.silesia_like(48 << 20, seed=21).tobytes()
+    comp = zlib.compress(plain, 6)
+    assert len(comp) > (8 << 20)
+    (tmp_path / "big.z").write_bytes(comp)
+    out = _run(driver, "i", 1, 1 << 26, 1 << 22, tmp_path / "big.z", tmp_path / "big.bin", len(plain), env={"COARSE_DRIVER_PARTS": "1"})
+    lines = out.splitlines()
+    assert lines[0] == "device %d %d" % (len(comp), len(plain)), lines
+    assert int(lines[1].split()[1]) >= 64, lines                       # really decoded in parts on the device
+    assert (tmp_path / "big.bin").read_bytes() == plain
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x10
+    try:
+        zlib.decompress(bytes(bad))
+        expected = None
+    except zlib.error as e:
+        expected = str(e)
+    (tmp_path / "bad.z").write_bytes(bytes(bad))
+    got = _run(driver, "i", 1, 1 << 26, 1 << 22, tmp_path / "bad.z", tmp_path / "o", len(plain))
+    assert got.startswith("data error: "), got
+    if expected:                                                       # classic zlib words the same checks the same way
+        assert got[len("data error: "):] in expected, (got, expected)
 
 
 @pytest.mark.gpu

@@ -23,6 +23,11 @@ struct zng_rocm_hook {
     uint32_t    *h_check;             // pinned
 };
 
+namespace zr {
+int inflate_large_device_only(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
+                              size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st);      // inflate_large.hip
+}
+
 namespace {
 constexpr uint32_t kHist = 32768u;
 
@@ -72,6 +77,44 @@ int roll_history(zng_rocm_hook *h, size_t n) {
 }
 
 bool stale(const zng_rocm_hook *h) { return !zr::ctx() || !h || h->generation != zr::ctx()->generation; }
+
+constexpr size_t kHookLargeMember = 4u << 20;         // compressed bytes from which a member is decoded on the device
+
+// 1 = stream end (outputs set), 0 = leave it to the host decoder, negative = error
+int hook_inflate_on_device(zng_rocm_hook *h, const uint8_t *in, size_t in_len, int check, uint32_t *check_value,
+                           const uint8_t **out, size_t *out_len, size_t *in_used) {
+    if (grow_device(&h->d_out, &h->out_cap, in_len, 0) != ZNG_ROCM_OK) return 0;          // the compressed bytes
+    if (hipMemcpyAsync(h->d_out, in, in_len, hipMemcpyHostToDevice, h->st) != hipSuccess) return 0;
+    size_t room = h->in_cap > 4 * in_len ? h->in_cap : 4 * in_len;                    // a guess; the call says what it needs
+    uint64_t n = 0;
+    size_t used = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (grow_device(&h->d_in, &h->in_cap, room, kHist) != ZNG_ROCM_OK) return 0;
+        const int rc = zr::inflate_large_device_only(h->d_out, in_len, h->hist_len ? h->d_in + kHist - h->hist_len : nullptr,
+                                                     h->hist_len, h->d_in + kHist, h->in_cap, &n, &used, h->st);
+        if (rc == 1) break;
+        if (rc == -5 && attempt == 0 && n > h->in_cap) {
+            room = (size_t)n;
+            continue;
+        }
+        return 0;
+    }
+    if (grow_pinned(&h->h_out, &h->h_cap, (size_t)n) != ZNG_ROCM_OK) return ZNG_ROCM_ENOMEM;
+    if (check && n) {
+        const int rc = check == 1 ? zng_rocm_adler32_dev(*check_value, h->d_in + kHist, (size_t)n, h->d_check, h->st)
+                                  : zng_rocm_crc32_dev(*check_value, h->d_in + kHist, (size_t)n, h->d_check, h->st);
+        if (rc != ZNG_ROCM_OK) return rc;
+        ZR_HIP(hipMemcpyAsync(h->h_check, h->d_check, 4, hipMemcpyDeviceToHost, h->st));
+    }
+    if (n) ZR_HIP(hipMemcpyAsync(h->h_out, h->d_in + kHist, (size_t)n, hipMemcpyDeviceToHost, h->st));
+    if (int r2 = roll_history(h, (size_t)n)) return r2;
+    ZR_HIP(hipStreamSynchronize(h->st));
+    if (check && n) *check_value = h->h_check[0];
+    *out = h->h_out;
+    *out_len = (size_t)n;
+    *in_used = used;
+    return 1;
+}
 }  // namespace
 
 using namespace zr;
@@ -191,6 +234,14 @@ int zng_rocm_hook_inflate(zng_rocm_hook *h, const uint8_t *in, size_t in_len, in
     *out_len = 0;
     *in_used = 0;
     if (msg) *msg = nullptr;
+    // A large member goes to the device whole (inflate_large.hip: block starts found there, one wavefront per part): the
+    // host decoder below manages ~0.8 GB/s of output on its one thread.  Anything but a clean end of stream -- truncated
+    // input, a data error, output larger than the estimate twice over -- is left to that decoder, whose status, message
+    // and byte counts are the reference's.
+    if (in_len >= kHookLargeMember) {
+        const int rc = hook_inflate_on_device(h, in, in_len, check, check_value, out, out_len, in_used);
+        if (rc != 0) return rc;
+    }
     zng_rocm_inflate_tokens tk;
     const int status = zng_rocm_inflate_tokens_decode_window(in, in_len, h->hist_len, &tk);
     if (status != 1) {                                   // not a complete stream: nothing is consumed, nothing produced

@@ -548,6 +548,17 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     return 1;
 }
 
+// The device path alone, for callers inside the library that have their own sequential decoder to fall back on
+// (hook.hip): 1 = done, 0 = irregular (nothing usable was written), -5 with *out_len set = dst_cap too small, other
+// negatives = errors.
+int inflate_large_device_only(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
+                              size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st) {
+    Workspace *ws = workspace_for(st);
+    if (!ws) return ZNG_ROCM_ENOMEM;
+    std::lock_guard<std::mutex> use(ws->mu);
+    return inflate_large_try(ws, d_src, src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, st);
+}
+
 }  // namespace zr
 
 using namespace zr;
