@@ -162,14 +162,22 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
 // Per lane in LDS: the code-length code as a 128-entry direct table (length << 5 | symbol).  Survivors are appended to
 // good[] (bit positions; the marker bit removed).
 constexpr int kValLanes = 64;
+__device__ void validate_one(const uint8_t *__restrict__ src, unsigned long long src_len, const unsigned long long c0, uint8_t *T,
+                             unsigned long long *__restrict__ good, uint32_t *__restrict__ ngood, uint32_t cap);
 __global__ __launch_bounds__(kValLanes)
 void validate_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src_len,
-                             const unsigned long long *__restrict__ cand, uint32_t n, unsigned long long *__restrict__ good,
-                             uint32_t *__restrict__ ngood, uint32_t cap) {
+                             const unsigned long long *__restrict__ cand, const uint32_t *__restrict__ ncand, uint32_t cand_cap,
+                             unsigned long long *__restrict__ good, uint32_t *__restrict__ ngood, uint32_t cap) {
     __shared__ uint8_t tab[kValLanes][128];
-    const uint32_t i = blockIdx.x * kValLanes + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long c0 = cand[i];
+    // the number of candidates is read here, not on the host: F1 -> F2 needs no round trip (the grid is fixed, each
+    // workgroup takes every gridDim.x-th group of 64 candidates; a lane's candidates are independent of each other)
+    const uint32_t n = *ncand < cand_cap ? *ncand : cand_cap;
+    for (uint32_t i = blockIdx.x * kValLanes + threadIdx.x; i < n; i += gridDim.x * kValLanes)
+        validate_one(src, src_len, cand[i], tab[threadIdx.x], good, ngood, cap);
+}
+
+__device__ void validate_one(const uint8_t *__restrict__ src, unsigned long long src_len, const unsigned long long c0, uint8_t *T,
+                             unsigned long long *__restrict__ good, uint32_t *__restrict__ ngood, uint32_t cap) {
     auto accept = [&]() {
         const uint32_t at = atomicAdd(ngood, 1u);
         if (at < cap) good[at] = c0 & ~(1ull << 63);
@@ -178,7 +186,6 @@ void validate_headers_kernel(const uint8_t *__restrict__ src, unsigned long long
         accept();
         return;
     }
-    uint8_t *T = tab[threadIdx.x];
     const unsigned long long bit = c0;
     unsigned long long w = bits_at_dev(src, src_len, bit + 3);
     const unsigned nlen = (unsigned)(w & 31) + 257, ndist = (unsigned)((w >> 5) & 31) + 1, ncode = (unsigned)((w >> 10) & 15) + 4;
@@ -383,20 +390,22 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     ZR_HIP(hipMemsetAsync(d_n, 0, 8, st));
     hipLaunchKernelGGL(find_headers_kernel, dim3(4096), dim3(256), 0, st, d_src, (unsigned long long)src_len, d_cand, d_n, cap1);
     ZR_HIP(hipGetLastError());
-    uint32_t n1 = 0;
-    ZR_HIP(hipMemcpyAsync(&n1, d_n, 4, hipMemcpyDeviceToHost, st));
-    ZR_HIP(hipStreamSynchronize(st));
-    if (n1 == 0 || n1 > cap1) return why("no candidate block starts, or far more than a deflate stream has");
-    hipLaunchKernelGGL(validate_headers_kernel, dim3((n1 + kValLanes - 1) / kValLanes), dim3(kValLanes), 0, st, d_src,
-                       (unsigned long long)src_len, d_cand, n1, d_good, d_n + 1, cap2);
+    hipLaunchKernelGGL(validate_headers_kernel, dim3(8192), dim3(kValLanes), 0, st, d_src, (unsigned long long)src_len, d_cand,
+                       d_n, cap1, d_good, d_n + 1, cap2);
     ZR_HIP(hipGetLastError());
-    uint32_t n2 = 0;
-    ZR_HIP(hipMemcpyAsync(&n2, d_n + 1, 4, hipMemcpyDeviceToHost, st));
+    // the count and (what is almost always all of) the list in one round trip
+    uint32_t n12[2] = {0, 0};
+    const uint32_t first = std::min<uint32_t>(cap2, 16384u);
+    std::vector<unsigned long long> good(first);
+    ZR_HIP(hipMemcpyAsync(n12, d_n, 8, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)first * 8, hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
+    const uint32_t n1 = n12[0], n2 = n12[1];
+    if (n1 == 0 || n1 > cap1) return why("no candidate block starts, or far more than a deflate stream has");
     if (n2 > cap2) return why("far more valid block headers than a deflate stream has");
-    std::vector<unsigned long long> good(n2);
-    if (n2) {
-        ZR_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+    good.resize(n2);
+    if (n2 > first) {
+        ZR_HIP(hipMemcpyAsync(good.data() + first, d_good + first, (size_t)(n2 - first) * 8, hipMemcpyDeviceToHost, st));
         ZR_HIP(hipStreamSynchronize(st));
     }
     std::sort(good.begin(), good.end());
