@@ -87,3 +87,37 @@ def test_output_cap():
     comp = c.compress(data) + c.flush()
     st, msg, out, used = inflate_util.oracle_inflate(comp, cap=100)
     assert st == -5 and msg == "output buffer full" and data.startswith(out)
+
+
+def test_crafted_token_streams_and_the_block_trace():
+    """tests/deflate_craft.py (the token-level stream builder the GPU edge-case tests use) against the oracle and CPython's
+    zlib, and the oracle's block trace (bit position and type of every block) against what the builder laid down"""
+    import zlib
+
+    import numpy as np
+
+    import deflate_craft as craft
+    import inflate_util
+    rng = np.random.default_rng(3)
+    toks = [("L", int(b)) for b in rng.integers(97, 123, size=3000)] + \
+           [("M", int(l), int(d)) for l, d in zip(rng.integers(3, 259, 300), rng.integers(1, 3000, 300))]
+    b = craft.Bits()
+    starts = []
+    plain = bytearray()
+    for kind in ("stored", "fixed", "stored", "fixed"):
+        starts.append((b.bit_length(), 0 if kind == "stored" else 1))
+        if kind == "stored":
+            data = bytes(rng.integers(0, 256, size=1000, dtype=np.uint8))
+            craft.stored_block(b, data, False)
+            plain += data
+        else:
+            craft.fixed_block(b, toks, False)
+            plain += craft.replay(toks, history=bytes(plain))
+    starts.append((b.bit_length(), 0))
+    craft.stored_block(b, b"", True)
+    comp = bytes(b.out)
+    assert zlib.decompressobj(-15).decompress(comp) == bytes(plain)
+    st, msg, out, used = inflate_util.oracle_inflate(comp, cap=len(plain))
+    assert (st, out, used) == (1, bytes(plain), len(comp))
+    status, blocks = inflate_util.oracle_block_starts(comp, len(plain))
+    assert status == 1 and blocks == starts

@@ -19,11 +19,15 @@ for _ in range(2):
     dst, clen = dfl.deflate_dev(src, level=6)
 torch.cuda.synchronize()
 s = buf.cpu().numpy().reshape(32, 16, 9).astype(np.float64)
-names = ["A reads + barrier", "insert turns", "C read + search", "DP parse", "exit map + barrier", "stitch chain", "path follow", "outputs + hist"]
-d = np.diff(s, axis=2)                                   # [batch, wave, phase]
+# one loop iteration of the two-batch pipeline: the front of batch k (stamps 0, 1, 2), its compares and the parse of batch
+# k - 1 in either order (no stamp between them: half the waves take one order, half the other), the finish of batch k - 1
+# (stamps 4 .. 7), its tokens out (8).  Stamp 3 is not set.
+names = ["A reads + barrier", "insert turns", "C read, compares (k) + parse (k-1)", "exit map + barrier", "stitch chain", "path follow",
+         "outputs + hist"]
+d = np.diff(s[:, :, [0, 1, 2, 4, 5, 6, 7, 8]], axis=2)   # [batch, wave, phase]
 print("ratio %.3f; cycles per phase (mean over 32 batches): min / mean / max over the 16 waves" % (n / clen))
 for k, nm in enumerate(names):
     m = d[:, :, k].mean(axis=0)
-    print("  %-22s %8.0f %8.0f %8.0f" % (nm, m.min(), m.mean(), m.max()))
+    print("  %-36s %8.0f %8.0f %8.0f" % (nm, m.min(), m.mean(), m.max()))
 tot = (s[1:, :, 0] - s[:-1, :, 0]).mean()
 print("  batch to batch          %8.0f" % tot)
