@@ -340,7 +340,9 @@ int  zng_rocm_inflate_resolve_window_dev(const uint32_t *d_tokens, size_t ntoken
                                          uint32_t window_len, void *stream);
 /* One-shot raw inflate (windowBits < 0): host stream in, plaintext left in device memory at d_dst.
  * Returns the zlib status of the decode (1 = Z_STREAM_END) or a negative ZNG_ROCM_E* / Z_* code;
- * *out_len = bytes produced.  -5 also when dst_cap is too small. */
+ * *out_len = bytes produced.  -5 also when dst_cap is too small.  A stream of 4 MiB and more is copied to the device and
+ * decoded there (as zng_rocm_inflate_large_dev; zng_rocm_inflate_large_last_parts() tells); anything irregular, and every
+ * smaller stream, is decoded on the calling thread (zng_rocm_inflate_tokens_decode) and resolved on the device. */
 int  zng_rocm_inflate_raw(const uint8_t *src, size_t src_len, uint8_t *d_dst, size_t dst_cap, uint64_t *out_len,
                           void *stream);
 
@@ -353,7 +355,7 @@ int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8
                                  uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
 
 /* ONE large raw stream that is ALREADY in device memory, inflated on the device: block starts are found on the device
- * (dynamic headers the decoder would accept, sync-flush markers), the stream is cut there into parts of >= 34 KiB, one
+ * (dynamic headers the decoder would accept, sync-flush markers, byte-aligned stored blocks), the stream is cut there into parts, one
  * wavefront decodes each part into 16-bit symbols (inffast_tpl.h:151-298 with the history still unknown), the parts are
  * chained from bit 0 and the context chain of zng_rocm_inflate_resolve_dev turns the symbols into bytes.  The host only
  * sorts a few thousand candidates and walks the chain.  Streams that offer nothing to cut at (fixed-Huffman blocks

@@ -84,3 +84,31 @@ def test_uncompress2_errors_use_reference_messages(one):
     kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "inflate_kat.json")))["zlib_stream"]
     rc, produced, consumed, msg = one.uncompress2_dev(bytes.fromhex(kat["hex"]), dst, fmt=one.ZLIB)
     assert rc == 0 and dst[:produced].cpu().numpy().tobytes() == kat["plaintext"].encode()
+
+
+def test_a_large_member_is_inflated_on_the_device(one):
+    """uncompress2 / inflate_raw of a member with 4 MiB and more of compressed bytes: up over PCIe once, then
+    inflate_large.hip (block starts found on the device, one wavefront per part); trailer checks, too-small destinations
+    and damaged streams answer as the sequential decoder does"""
+    torch = torch_mod()
+    zr = product()
+    inf = importlib.import_module("zlib-ng_amd.inflate")
+    plain = synth.silesia_like(40 << 20, seed=31).tobytes()
+    gz = gzip.compress(plain, 6)
+    assert len(gz) > (6 << 20)
+    dst = torch.zeros(len(plain) + 64, dtype=torch.uint8, device="cuda")
+    rc, produced, consumed, msg = one.uncompress2_dev(gz, dst, fmt=one.GZIP)
+    assert (rc, produced, consumed) == (0, len(plain), len(gz)), (rc, msg)
+    assert zr.rocm.lib().zng_rocm_inflate_large_last_parts() >= 32             # decoded in parts on the device
+    assert dst[:produced].cpu().numpy().tobytes() == plain
+    bad = bytearray(gz)
+    bad[-6] ^= 1                                                              # CRC-32 in the trailer
+    assert one.uncompress2_dev(bytes(bad), dst, fmt=one.GZIP)[::3] == (-3, "incorrect data check")
+    small = torch.zeros(len(plain) - 1, dtype=torch.uint8, device="cuda")
+    assert one.uncompress2_dev(gz, small, fmt=one.GZIP)[0] == -5               # Z_BUF_ERROR
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    stream = raw.compress(plain) + raw.flush()
+    rc, produced = inf.inflate_raw(stream[:len(stream) * 3 // 4], dst)         # truncated: the sequential decoder's answer
+    assert rc == -5 and zr.rocm.lib().zng_rocm_last_error().decode() == "input ended before the final block"
+    rc, produced = inf.inflate_raw(stream, dst)
+    assert (rc, produced) == (1, len(plain)) and dst[:produced].cpu().numpy().tobytes() == plain

@@ -73,6 +73,7 @@ enum ScratchSlot {
     kScrLargeParts,         // device: jobs | starts | results | symbol slots of the parts
     kScrLargeRetry,         // device: worst-case slots of the parts that overflowed theirs
     kScrLargeSym,           // device: segs | copies | the stream's symbol array
+    kScrLargeSrc,           // device: the compressed bytes of a large HOST-resident stream (zng_rocm_inflate_raw*)
     kScrCount
 };
 

@@ -360,6 +360,9 @@ void compact_parts_kernel(const PartCopy *__restrict__ parts, uint16_t *__restri
     }
 }
 
+// inflate_resolve.hip: the sequential decoder + device resolve
+int inflate_raw_window_sequential(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
+                                  size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st);
 // inflate_resolve.hip: symbols -> bytes (window in front, context chain, translate)
 int inflate_resolve_symbols(const uint64_t *d_segs, size_t nsegs, uint16_t *sym, uint8_t *d_out, const uint8_t *d_window,
                             uint32_t window_len, hipStream_t st);
@@ -557,6 +560,27 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     return 1;
 }
 
+// A large stream that is in HOST memory (zng_rocm_inflate_raw*, and with them uncompress2 and the gzip / zlib one-shots):
+// up over PCIe once and through the device path; 0 = not done here (the caller's sequential decoder takes it).
+int inflate_large_from_host(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
+                            size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st) {
+    Workspace *ws = workspace_for(st);
+    if (!ws) return 0;
+    std::lock_guard<std::mutex> use(ws->mu);
+    uint8_t *d_src = nullptr;
+    if (scratch_reserve(ws, kScrLargeSrc, src_len + 64, false, (void **)&d_src) != ZNG_ROCM_OK) return 0;
+    if (hipMemcpyAsync(d_src, src, src_len, hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    uint64_t n = 0;
+    size_t used = 0;
+    const int rc = inflate_large_try(ws, d_src, src_len, d_window, window_len, d_dst, dst_cap, &n, &used, st);
+    if (rc == 1 || rc == -5) {
+        if (out_len) *out_len = n;
+        if (in_used) *in_used = used;
+        return rc;
+    }
+    return 0;
+}
+
 // The device path alone, for callers inside the library that have their own sequential decoder to fall back on
 // (hook.hip): 1 = done, 0 = irregular (nothing usable was written), -5 with *out_len set = dst_cap too small, other
 // negatives = errors.
@@ -609,7 +633,7 @@ int zng_rocm_inflate_large_dev(const uint8_t *d_src, size_t src_len, const uint8
         ZR_HIP(hipMemcpyAsync(host.data(), d_src, src_len, hipMemcpyDeviceToHost, st));
         ZR_HIP(hipStreamSynchronize(st));
     }
-    return zng_rocm_inflate_raw_window(host.data(), src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, stream);
+    return inflate_raw_window_sequential(host.data(), src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, st);
 }
 
 }  // extern "C"
