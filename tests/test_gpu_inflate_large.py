@@ -125,3 +125,45 @@ def test_small_and_highly_compressible_streams(mods):
         st, n, used, _ = inf.inflate_large_dev(src, dst)
         assert (st, n, used) == (1, len(plain), len(comp))
         assert dst.cpu().numpy().tobytes() == plain
+
+
+def test_mutated_large_streams_agree_with_the_oracle(mods):
+    """40 mutations of a 3 MiB stream (bit flips, byte edits, a zeroed run, truncations -- in dynamic, stored and fixed
+    blocks): status, message, bytes produced and the bytes themselves as the oracle inflater gives them.  A mutation may
+    hide a block start, fake one, or leave a valid stream with other contents; whatever the device path makes of it, the
+    answer has to be the sequential one."""
+    import inflate_util
+    torch, inf, _ = mods
+    zr = importlib.import_module("zlib-ng_amd")
+    rng = np.random.default_rng(0xBADC0DE)
+    plain = synth.silesia_like(3 << 20, seed=41, seg_bytes=256 << 10).tobytes()
+    comp = _raw(plain, 6)
+    assert len(comp) > (256 << 10)
+    dst = torch.zeros(len(plain) + 4096, dtype=torch.uint8, device="cuda")
+    regular = 0
+    for k in range(40):
+        bad = bytearray(comp)
+        kind = k % 4
+        at = int(rng.integers(64, len(bad) - 64))
+        if kind == 0:
+            bad[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            bad[at] = int(rng.integers(0, 256))
+            bad[at + 1] = int(rng.integers(0, 256))
+        elif kind == 2:
+            bad[at:at + 16] = bytes(16)
+        else:
+            bad = bad[:at]
+        bad = bytes(bad)
+        ost, omsg, oout, oused = inflate_util.oracle_inflate(bad, cap=len(plain) + 4096)
+        src = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).cuda()
+        dst.zero_()
+        st, n, used, parts = inf.inflate_large_dev(src, dst)
+        assert st == ost, (k, kind, at, st, ost, omsg)
+        if ost == 1:
+            regular += 1
+            assert (n, used) == (len(oout), oused), (k, kind, at)
+            assert dst[:n].cpu().numpy().tobytes() == oout, (k, kind, at)
+        elif ost == -3:
+            assert zr.rocm.lib().zng_rocm_last_error().decode() == omsg, (k, kind, at)
+    assert regular >= 1                                    # some damage leaves a valid stream (a literal changed)
