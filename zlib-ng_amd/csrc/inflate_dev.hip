@@ -67,15 +67,18 @@ __device__ __forceinline__ uint32_t zr_idx(uint32_t i, uint32_t n) {
 constexpr uint32_t kLongMark = (0xfffu << 4), kBadMark = (0xffeu << 4) | 1u;
 __device__ __forceinline__ uint32_t make_entry(uint32_t nbits, uint32_t sym) { return nbits | (sym << 4); }
 
-constexpr int kLitRoot = 10, kDistRoot = 9, kClRoot = 7;
+constexpr int kLitRootStream = 10, kLitRootPart = 10, kClRoot = 7;   // (a 9-bit literal root in part mode -- a 13th wave per CU -- was slower: 6.1 -> 6.8 ms, too many codes take the long path)
+// root bits of the distance table: 9 for whole streams (16 per CU fit either way), 8 in part mode, where the 1 KiB it saves
+// is the twelfth wave of a CU (part kernel 6.6 -> 6.1 ms; whole streams lose 2.5 % with 8: more codes take the long path)
+constexpr int kDistRootStream = 9, kDistRootPart = 8;
 // order in which the code-length code's lengths are sent (RFC 1951 3.2.7; inflate.c:832-833 holds the same permutation)
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 constexpr int kCodeLit = 0, kCodeDist = 1, kCodeCl = 2;
 
-template <int RING, typename T>
+template <int RING, typename T, int DR, int LR>
 struct InflateLds {
-    uint16_t lit[1 << kLitRoot];
-    uint32_t dist[1 << kDistRoot];      // wide entries: code length | extra bits << 4 | base distance << 8 (wide_distance)
+    uint16_t lit[1 << LR];
+    uint32_t dist[1 << DR];             // wide entries: code length | extra bits << 4 | base distance << 8 (wide_distance)
     uint16_t cl[1 << kClRoot];
     uint32_t cnt[3][16], first[3][16], offs[3][16], run[16];
     uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[32];
@@ -423,7 +426,8 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     // bytes not yet flushed never exceed kFlushAt + 16 + max(258, kStoredPiece); a match of 258 more must not overwrite them
     static_assert(kFlushAt + 16 + kStoredPiece + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
     static_assert(kFlushAt + 64 < kNear, "a source beyond kNear must have left the ring (the fast loop reads it from HBM)");
-    __shared__ InflateLds<RING, T> L;
+    constexpr int kDistRoot = PART ? kDistRootPart : kDistRootStream, kLitRoot = PART ? kLitRootPart : kLitRootStream;
+    __shared__ InflateLds<RING, T, kDistRoot, kLitRoot> L;
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
