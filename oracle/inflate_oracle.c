@@ -53,6 +53,7 @@ typedef struct {
     uint16_t count[MAXBITS + 1];
     uint16_t symbol[MAXL];
     int empty;
+    int incomplete;             /* one code of length 1, the other 1-bit pattern unused */
 } huff;
 
 /* returns 0 ok, -1 invalid per inftrees.c:108-131 (`is_codes` = the CODES type) */
@@ -65,6 +66,7 @@ static int build(huff *h, const uint16_t *lens, int n, int is_codes) {
     while (max >= 1 && h->count[max] == 0)
         max--;
     h->empty = (max == 0);
+    h->incomplete = 0;
     if (h->empty)
         return 0;                                   /* inftrees.c:114-122 */
     int left = 1;
@@ -76,6 +78,7 @@ static int build(huff *h, const uint16_t *lens, int n, int is_codes) {
     }
     if (left > 0 && (is_codes || max != 1))
         return -1;                                  /* incomplete */
+    h->incomplete = left > 0 && !h->empty;
     offs[1] = 0;
     for (int len = 1; len < MAXBITS; len++)
         offs[len + 1] = offs[len] + h->count[len];
@@ -85,11 +88,18 @@ static int build(huff *h, const uint16_t *lens, int n, int is_codes) {
     return 0;
 }
 
-/* canonical decode, one bit at a time; -1 = no such code, -2 = out of input */
+/* canonical decode, one bit at a time; -1 = no such code, -2 = out of input.
+ * An empty set, and the one incomplete set inflate_table lets through (a single code of length 1), are one-bit tables in
+ * the reference whose unused entries read {op 64, bits 1} (inftrees.c:114-122, :286-293): the invalid code is seen after
+ * ONE bit -- with more input missing that is still a data error, not a request for input (inflate.c:990-1003). */
 static int decode(bitreader *br, const huff *h) {
     int code = 0, first = 0, index = 0;
-    if (h->empty)
-        return -1;
+    if (h->empty || h->incomplete) {
+        int bit = getbits(br, 1);
+        if (br->starved)
+            return -2;
+        return (h->empty || bit) ? -1 : h->symbol[0];
+    }
     for (int len = 1; len <= MAXBITS; len++) {
         code |= getbits(br, 1);
         if (br->starved)

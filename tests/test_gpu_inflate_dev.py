@@ -310,3 +310,26 @@ def test_fifty_thousand_tiny_streams(inf):
     r = wrapped.results.cpu()
     assert (r[:, 2] == 1).all() and (r[:, 3] == 0).all() and r[:, 1].tolist() == [len(b) for b in blobs]
     assert dst[:opos].cpu().numpy().tobytes() == b"".join(plains)
+
+
+def test_every_last_byte_at_every_truncation_of_tiny_streams(inf):
+    """the end of a truncated stream, exhaustively: a fixed-Huffman and a dynamic stream cut at every length, the last byte
+    replaced by each of its 256 values.  Bits behind the input read as zeros in the device decoder; what it makes of them
+    must not show -- e.g. an invalid 5-bit distance code half of which is padding is "input ended", not a data error
+    (inflate.c's NEEDBITS / PULLBYTE ask for input first).  Found by tools/micro/inflate_soak.py (stream 6360408064067c00e5)."""
+    seeds = [bytes.fromhex("6360408064067c0000"),                                   # fixed: a run of zeros with one 'c'
+             _raw(b"abcabcabcabd" * 3 + bytes(range(40)), 9),                        # fixed or dynamic, zlib's choice
+             _raw(synth.silesia_like(600, seed=4).tobytes(), 6)]                     # dynamic
+    streams = []
+    for s in seeds:
+        for cut in range(1, len(s) + 1):
+            for v in range(256):
+                streams.append(s[:cut - 1] + bytes([v]))
+    cap = 4096
+    rows, outs = _run(inf, streams, [cap] * len(streams))
+    differ = []
+    for s, r, o in zip(streams, rows, outs):
+        ost, omsg, oout, oused = inflate_util.oracle_inflate(s, cap=cap)
+        if (r[0], r[3]) != (ost, omsg) or (ost == 1 and (o != oout or r[2] != oused)):
+            differ.append((s.hex(), r, (ost, omsg)))
+    assert not differ, (len(differ), differ[:5])

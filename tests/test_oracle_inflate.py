@@ -121,3 +121,18 @@ def test_crafted_token_streams_and_the_block_trace():
     assert (st, out, used) == (1, bytes(plain), len(comp))
     status, blocks = inflate_util.oracle_block_starts(comp, len(plain))
     assert status == 1 and blocks == starts
+
+
+def test_invalid_code_of_an_incomplete_set_is_seen_after_one_bit():
+    """two truncated streams tools/micro/inflate_soak.py found: a distance set with ONE code (length 1) and the other 1-bit
+    pattern in the stream.  The reference's table has that entry as {op 64, bits 1} (inftrees.c:286-293), so the error is
+    "invalid distance code" even though the input ends right behind it; classic zlib says the same"""
+    import zlib
+
+    import inflate_util
+    for hexs in ("25c1310ac2401000c059175268914a14b1b010598bfb6f72f9ac67328c", "edc1010d000000c2a0da8f6f0e3786"):
+        s = bytes.fromhex(hexs)
+        with pytest.raises(zlib.error, match="invalid distance code"):
+            zlib.decompressobj(-15).decompress(s)
+        st, msg, _, _ = inflate_util.oracle_inflate(s, cap=70000)
+        assert (st, msg) == (-3, "invalid distance code")

@@ -100,11 +100,14 @@ __device__ __forceinline__ void distance_of(uint32_t k, uint32_t *base, uint32_t
 
 // the distance table's decode-loop form: base and extra-bit count ride in the entry (the loop is scalar-issue bound and
 // the arithmetic of distance_of is 11 scalar instructions per match; 1 KiB more LDS per stream)
-constexpr uint32_t kLongWide = 0xfffffff0u, kBadWide = 0xffffffe1u;
+// kBadWide | n: an invalid code of n bits -- symbols 30, 31, or the unused entry of an incomplete set (1 bit).  The length
+// matters at the end of a truncated stream: the reference reports an invalid code only when all of its bits are input
+// (inflate.c's NEEDBITS / PULLBYTE loops ask for more first), and bits behind the input read as zeros here.
+constexpr uint32_t kLongWide = 0xfffffff0u, kBadWide = 0xffffffe0u;
 __device__ __forceinline__ uint32_t wide_distance(uint32_t e) {           // e: a 16-bit entry
     if (e == kLongMark) return kLongWide;
     const uint32_t sym = e >> 4;
-    if (sym > 29u) return kBadWide;                                           // 30, 31 (inftrees.c:48-49), no code
+    if (sym > 29u) return kBadWide | (e & 15u);                               // 30, 31 (inftrees.c:48-49), no code
     uint32_t b = 0, x = 0;
     distance_of(sym, &b, &x);
     return (e & 15u) | (x << 4) | (b << 8);
@@ -667,12 +670,12 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                 }
                 uint32_t rep, val = 0;
                 if (sym == 16) {
+                    rep = 3u + ((uint32_t)hold & 3u);                 // NEEDBITS(here.bits + 2) comes first (inflate.c:856-864):
+                    hold >>= 2;                                       // at the end of a truncated stream the answer is
+                    cnt -= 2;                                         // "input ended", not this error
                     if (have == 0) { msg = kMsgBitRepeat; break; }
                     wave_sync();
                     val = uni(L.lens[have - 1]);
-                    rep = 3u + ((uint32_t)hold & 3u);
-                    hold >>= 2;
-                    cnt -= 2;
                 } else if (sym == 17) {
                     rep = 3u + ((uint32_t)hold & 7u);
                     hold >>= 3;
@@ -768,7 +771,10 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     continue;
                 }
                 const uint32_t sym = e >> 4, nb = e & 15u;
-                if (sym > 285u) { msg = kMsgLitLenCode; break; }                      // 286, 287 (inftrees.c:44-45), no code
+                if (sym > 285u) {                                                     // 286, 287 (inftrees.c:44-45), no code
+                    msg = bit_pos() + nb > 8ull * in_len ? kMsgStarved : kMsgLitLenCode;   // (its bits must all be input)
+                    break;
+                }
                 hold >>= nb;
                 cnt -= nb;
                 if (sym == 256u) break;                                               // end of block
@@ -790,7 +796,10 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                 uint32_t d = uni(L.dist[(uint32_t)hold & ((1u << kDistRoot) - 1u)]);
                 if (d >= kBadWide) {
                     if (d == kLongWide) d = wide_distance(long_code(L, kCodeDist, kDistRoot, L.sorted_dist, hold));
-                    if (d >= kBadWide) { msg = kMsgDistCode; break; }
+                    if (d >= kBadWide) {
+                        msg = bit_pos() + (d & 15u) > 8ull * in_len ? kMsgStarved : kMsgDistCode;
+                        break;
+                    }
                 }
                 const uint32_t dnb = d & 15u, dxb = (d >> 4) & 15u;
                 hold >>= dnb;
