@@ -183,7 +183,7 @@ int main(int argc, char **argv) {
         const int sync_every = atoi(argv[6]);
         uint8_t *in = read_file(argv[7], &n);
         if (!in) return 2;
-        cap = n + n / 4 + (n / in_chunk + 4) * 4096 + 65536;
+        cap = n + n / 4 + (n / in_chunk + 4) * 4096 + 65536 + out_chunk;
         out = malloc(cap);
         DEFLATE_RESET_KEEP_HOOK(&strm);
         size_t fed = 0;
