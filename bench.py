@@ -495,8 +495,9 @@ def run_single_stream_legs(args, zr, torch, dist, dev, world, rank):
                                 "symbols resolved by the context chain; host: sort + chain walk on 1 thread" % (clen / 2**20),
                     "value": round(world * gb / t_large, 2), "unit": "GB/s of output", "ms_per_stream": round(t_large * 1e3, 2),
                     "in_GBps": round(world * clen / 1e9 / t_large, 2), "parts": big["rc"][3], "host_threads": 1,
-                    "host_decode": {"what": "the same stream handed over as a HOST buffer: token decode on %d host threads cut at found "
-                                            "block boundaries, tokens over PCIe, device resolve" % T,
+                    "host_decode": {"what": "the same stream handed over as a HOST buffer to zng_rocm_inflate_raw_threads: token decode on "
+                                            "%d host threads cut at found block boundaries, tokens over PCIe, device resolve; with ONE "
+                                            "thread the call copies the stream up and decodes it on the device (PCIe inclusive)" % T,
                                     "GBps_of_output": round(world * gb / t_inf, 2), "ms_per_stream": round(t_inf * 1e3, 2),
                                     "host_threads": T, "parts_joined": parts, "one_host_thread_GBps": round(gb / t_inf1, 2)},
                     "scaling": "replicas only" if world > 1 else "single",
@@ -543,6 +544,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shard-mib", type=int, default=SHARD_BYTES >> 20)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--settle", type=int, default=SETTLE_LAUNCHES, help="untimed launches in front of the warm-up (disclosed in the line)")
     ap.add_argument("--workload", choices=("all", "checksum", "streams"), default="all",
                     help="all = BASELINE.json configs[1] as the top-level line (the driver's contract) plus the "
                          "configs[4] `streams` object; checksum = the top-level line only; streams = configs[4] only, "
@@ -658,7 +660,7 @@ def main():
     simple = os.environ.get("ZNG_BENCH_SIMPLE_EXCHANGE") == "1"
 
     # ---- settle phase: untimed, disclosed (`settle_launches`) --------------------------------------------------
-    for _ in range(SETTLE_LAUNCHES):
+    for _ in range(args.settle):
         zr.adler32_crc32_dev(buf, out, adler=1, crc=0)
     torch.cuda.synchronize()
 
@@ -774,7 +776,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "settle_launches": SETTLE_LAUNCHES,
+            "settle_launches": args.settle,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -790,7 +792,7 @@ def main():
                 "checksums": ["%08x" % result[0], "%08x" % result[1]],
                 "rehearsal_same_gpu": rehearse,
                 "settle": "%d untimed launches of the same kernel before the %d warm-up steps (clock settle, not part of "
-                          "any timed figure)" % (SETTLE_LAUNCHES, args.warmup),
+                          "any timed figure)" % (args.settle, args.warmup),
             },
             "roofline": {
                 "bound": "hbm",
