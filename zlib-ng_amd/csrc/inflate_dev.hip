@@ -15,8 +15,9 @@
 //     literals and near matches never touch HBM, the ring leaves in aligned 16-byte stores, and only a match that
 //     reaches further back than the ring reads its source from HBM (the stream's own earlier output, or the
 //     dictionary / previous window that precedes `out`).
-// Single streams (cfg3) stay with the host-decoded token path (inflate_host.cpp + inflate_resolve.hip), whose host
-// side scales with threads; this kernel scales with the NUMBER of streams.
+// This kernel scales with the NUMBER of streams; ONE large stream is cut into parts at block starts found on the device
+// and every part is a job of this kernel in part mode (inflate_large.hip).  The decode loop itself is hand-written
+// (ZR_INFLATE_FAST_LOOP below).
 //
 // Status and messages are the reference's (inflate.c strm->msg texts, via zng_rocm_inflate_message).
 #include <hip/hip_runtime.h>
