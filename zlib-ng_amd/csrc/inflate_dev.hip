@@ -221,7 +221,7 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
 //   * a refill of the bit buffer from the 64 fetched words (it leaves when the 64 are used up);
 //   * a literal whose code fits the root table: into the waiting run (`lit`, literal j in lane j);
 //   * a length symbol whose code fits the root table + a distance whose code fits its root table, when the copy is one of
-//     the common shapes and nothing else is due (len <= 64, op + len <= oplim: room in `out`, no flush): source in the
+//     the common shapes and nothing else is due (op + len <= oplim: room in `out`, no flush; 64 per pass): source in the
 //     ring without overlap (dist <= kNear, dist >= len), source already flushed (dist > kNear: read back from HBM), or
 //     -- parts only -- source in front of the part (ZR_INFLATE_BEFORE_PART).
 // Anything else leaves the loop with `stage` = what has been consumed of the next symbol: 0 nothing, 1 the length (`len`
@@ -320,9 +320,7 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_add_u32 %[dist], %[dist], %[t0]\n\t"                                                                            \
     "s_lshr_b64 s[40:41], s[40:41], %[t1]\n\t"                                                                         \
     "s_sub_u32 %[cnt], %[cnt], %[t1]\n\t"                                                                              \
-    /* a copy of at most 64 with nothing else due (room in `out`, no flush)? */                                       \
-    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
-    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
+    /* nothing else due (room in `out`, no flush)? */                                                                 \
     "s_add_u32 %[t1], %[op], %[len]\n\t"                                                                               \
     "s_cmp_gt_u32 %[t1], %[oplim]\n\t"                                                                                 \
     "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
@@ -362,6 +360,31 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
     WR " %[va], %[vb]\n\t"                                                                                             \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
+    "s_cbranch_scc1 L_nearmore_%=\n\t"                                                                                 \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    /* 65 .. 258: the other chunks of 64 (no overlap: the chunks are independent of each other) */                    \
+    "L_nearmore_%=:\n\t"                                                                                               \
+    "s_mov_b32 %[t1], 64\n\t"                                                                                          \
+    "L_nearloop_%=:\n\t"                                                                                               \
+    "s_sub_u32 %[t0], %[len], %[t1]\n\t"                                                                               \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_add_u32 %[e], %[op], %[a0]\n\t"                                                                                 \
+    "s_add_u32 %[e], %[e], %[t1]\n\t"                                                                                  \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_subrev_u32 %[vb], %[dist], %[va]\n\t"                                                                           \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_and_b32 %[vb], %[mask], %[vb]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "v_lshl_add_u32 %[vb], %[vb], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    RD " %[vb], %[vb]\n\t"                                                                                             \
+    "s_add_u32 %[t1], %[t1], 64\n\t"                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_lt_u32 %[t1], %[len]\n\t"                                                                                   \
+    "s_cbranch_scc1 L_nearloop_%=\n\t"                                                                                 \
     "s_branch L_top_%=\n\t"                                                                                            \
     /* source behind the ring's reach: it has been flushed (op - flushed < kFlushAt < kNear - 64), so it is in HBM,   \
        and the flush had its stores acknowledged */                                                                   \
@@ -375,6 +398,30 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_waitcnt vmcnt(0)\n\t"                                                                                           \
     WR " %[va], %[vb]\n\t"                                                                                             \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
+    "s_cbranch_scc1 L_farmore_%=\n\t"                                                                                  \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    "L_farmore_%=:\n\t"                                                                                                \
+    "s_mov_b32 %[t1], 64\n\t"                                                                                          \
+    "L_farloop_%=:\n\t"                                                                                                \
+    "s_sub_u32 %[t0], %[len], %[t1]\n\t"                                                                               \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_add_u32 %[e], %[op], %[t1]\n\t"                                                                                 \
+    "s_sub_u32 %[t0], %[e], %[dist]\n\t"                                                                               \
+    "s_add_u32 %[e], %[e], %[a0]\n\t"                                                                                  \
+    "v_add_u32 %[vb], %[t0], %[lane]\n\t"                                                                              \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_lshlrev_b32 %[vb], %[sh], %[vb]\n\t"                                                                            \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vb], %[vb], %[outp]\n\t"                                                                                    \
+    "s_add_u32 %[t1], %[t1], 64\n\t"                                                                                   \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                           \
+    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_lt_u32 %[t1], %[len]\n\t"                                                                                   \
+    "s_cbranch_scc1 L_farloop_%=\n\t"                                                                                  \
     "s_branch L_top_%=\n\t"                                                                                            \
     "L_before_%=:\n\t"                                                                                                 \
     BEFORE                                                                                                             \
@@ -407,6 +454,27 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "ds_write_b16 %[va], %[vb]\n\t"                                                                                    \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
     "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
+    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
+    "s_cbranch_scc1 L_beforemore_%=\n\t"                                                                               \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    "L_beforemore_%=:\n\t"                                                                                             \
+    "s_mov_b32 %[t0], 64\n\t"                                                                                          \
+    "L_beforeloop_%=:\n\t"                                                                                             \
+    "s_sub_u32 %[e], %[len], %[t0]\n\t"                                                                                \
+    "v_cmp_gt_u32 vcc, %[e], %[lane]\n\t"                                                                              \
+    "s_add_u32 %[e], %[op], %[a0]\n\t"                                                                                 \
+    "s_add_u32 %[e], %[e], %[t0]\n\t"                                                                                  \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "s_add_u32 %[e], %[t1], %[t0]\n\t"                                                                                 \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_add_u32 %[vb], %[e], %[lane]\n\t"                                                                               \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    "ds_write_b16 %[va], %[vb]\n\t"                                                                                    \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_add_u32 %[t0], %[t0], 64\n\t"                                                                                   \
+    "s_cmp_lt_u32 %[t0], %[len]\n\t"                                                                                   \
+    "s_cbranch_scc1 L_beforeloop_%=\n\t"                                                                               \
     "s_branch L_top_%=\n\t"
 
 // PART = false: a job is a whole stream, the output is bytes (the many-stream entry points).
@@ -429,7 +497,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     constexpr uint32_t kNear = RING - 258;               // a source this close is still in the ring while the match is written
     // bytes not yet flushed never exceed kFlushAt + 16 + max(258, kStoredPiece); a match of 258 more must not overwrite them
     static_assert(kFlushAt + 16 + kStoredPiece + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
-    static_assert(kFlushAt + 64 < kNear, "a source beyond kNear must have left the ring (the fast loop reads it from HBM)");
+    static_assert(kFlushAt + 258 < kNear, "a source beyond kNear must have left the ring (the fast loop reads it from HBM)");
     constexpr int kDistRoot = PART ? kDistRootPart : kDistRootStream, kLitRoot = PART ? kLitRootPart : kLitRootStream;
     __shared__ InflateLds<RING, T, kDistRoot, kLitRoot> L;
     const int lane = threadIdx.x;
