@@ -350,8 +350,10 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_cmp_gt_u32 %[dist], %[near]\n\t"                                                                                \
     "s_cbranch_scc1 L_far_%=\n\t"                                                                                      \
     "s_cmp_lt_u32 %[dist], %[len]\n\t"                                                                                 \
-    "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
-    /* source in the ring, no overlap */                                                                              \
+    "s_cbranch_scc1 L_overlap_%=\n\t"                                                                                  \
+    /* source in the ring; no overlap, or a distance of 64 and more (every pass of 64 then reads what is already there: \
+       LDS operations of one wave execute in order) */                                                                \
+    "L_plain_%=:\n\t"                                                                                                  \
     "v_and_b32 %[vb], %[mask], %[vb]\n\t"                                                                              \
     "v_lshl_add_u32 %[vb], %[vb], %[sh], %[ringb]\n\t"                                                                 \
     "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
@@ -385,6 +387,61 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
     "s_cmp_lt_u32 %[t1], %[len]\n\t"                                                                                   \
     "s_cbranch_scc1 L_nearloop_%=\n\t"                                                                                 \
+    "s_branch L_top_%=\n\t"                                                                                            \
+    /* dist < len and dist < 64: the copy repeats the dist bytes in front of it (runs, short periods -- a block of zeros is \
+       nothing else).  Lane j of a pass at offset o reads pattern byte (o + j) mod dist from [op - dist, op), which no pass \
+       writes: r = j mod dist by six compare-free steps (r = min(r, r - dist * 2^k), unsigned), then r += 64 mod dist per \
+       pass. */                                                                                                       \
+    "L_overlap_%=:\n\t"                                                                                                \
+    "s_cmp_gt_u32 %[dist], 63\n\t"                                                                                     \
+    "s_cbranch_scc1 L_plain_%=\n\t"                                                                                    \
+    "s_lshl_b32 %[t0], %[dist], 5\n\t"                                                                                 \
+    "v_subrev_u32 %[vb], %[t0], %[lane]\n\t"                                                                           \
+    "s_lshl_b32 %[t0], %[dist], 4\n\t"                                                                                 \
+    "v_min_u32 %[vr], %[vb], %[lane]\n\t"                                                                              \
+    "v_subrev_u32 %[vb], %[t0], %[vr]\n\t"                                                                             \
+    "s_lshl_b32 %[t0], %[dist], 3\n\t"                                                                                 \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "v_subrev_u32 %[vb], %[t0], %[vr]\n\t"                                                                             \
+    "s_lshl_b32 %[t0], %[dist], 2\n\t"                                                                                 \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "v_subrev_u32 %[vb], %[t0], %[vr]\n\t"                                                                             \
+    "s_lshl_b32 %[t0], %[dist], 1\n\t"                                                                                 \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "v_subrev_u32 %[vb], %[t0], %[vr]\n\t"                                                                             \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "v_subrev_u32 %[vb], %[dist], %[vr]\n\t"                                                                           \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
+    "s_nop 0\n\t"                                                                                                      \
+    "v_readlane_b32 %[t2], %[vr], 63\n\t"                                                                              \
+    "s_mov_b32 %[t1], 0\n\t"                                                                                           \
+    "s_add_u32 %[t2], %[t2], 1\n\t"                                                                                    \
+    "s_cmp_eq_u32 %[t2], %[dist]\n\t"                                                                                  \
+    "s_cselect_b32 %[t2], 0, %[t2]\n\t"                                                                                \
+    "L_patloop_%=:\n\t"                                                                                                \
+    "s_sub_u32 %[t0], %[len], %[t1]\n\t"                                                                               \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_add_u32 %[e], %[op], %[a0]\n\t"                                                                                 \
+    "s_sub_u32 %[t0], %[e], %[dist]\n\t"                                                                               \
+    "s_add_u32 %[e], %[e], %[t1]\n\t"                                                                                  \
+    "v_add_u32 %[vb], %[t0], %[vr]\n\t"                                                                                \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_and_b32 %[vb], %[mask], %[vb]\n\t"                                                                              \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[vb], %[vb], %[sh], %[ringb]\n\t"                                                                 \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    RD " %[vb], %[vb]\n\t"                                                                                             \
+    "s_add_u32 %[t1], %[t1], 64\n\t"                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "v_add_u32 %[vr], %[t2], %[vr]\n\t"                                                                                \
+    "v_subrev_u32 %[vb], %[dist], %[vr]\n\t"                                                                           \
+    "s_cmp_lt_u32 %[t1], %[len]\n\t"                                                                                   \
+    "v_min_u32 %[vr], %[vb], %[vr]\n\t"                                                                                \
+    "s_cbranch_scc1 L_patloop_%=\n\t"                                                                                  \
     "s_branch L_top_%=\n\t"                                                                                            \
     /* source behind the ring's reach: it has been flushed (op - flushed < kFlushAt < kNear - 64), so it is in HBM,   \
        and the flush had its stores acknowledged */                                                                   \
@@ -784,7 +841,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             }
             uint32_t stage, len = 0, dist = 0;
             {
-                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, ee, opx, va, vb;
+                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, t2, ee, opx, va, vb, vr;
                 // no flush is due and the match fits `out` while op + len <= oplim (what service() would test)
                 const uint32_t fl = flushed + kFlushAt - 1u, oplim = out_cap < fl ? out_cap : fl;
                 const unsigned long long out_addr = (unsigned long long)(uintptr_t)J.out;
@@ -795,7 +852,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u8", "ds_write_b8", "global_load_ubyte", ZR_INFLATE_BEFORE_STREAM)
                                  : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
-                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb)
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr)
                                  : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(0),
                                    [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
@@ -804,7 +861,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u16", "ds_write_b16", "global_load_ushort", ZR_INFLATE_BEFORE_PART)
                                  : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
-                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb)
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr)
                                  : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(1),
                                    [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
