@@ -446,39 +446,95 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     /* source behind the ring's reach: it has been flushed (op - flushed < kFlushAt < kNear - 64), so it is in HBM,   \
        and the flush had its stores acknowledged */                                                                   \
     "L_far_%=:\n\t"                                                                                                    \
+    /* up to five passes of 64: ALL their loads first (one address register, instruction offsets 64, 128, ... elements), \
+       one wait, then the writes -- a pass at a time this was a memory round trip per 64 symbols, and a block of long     \
+       copies at a distance just beyond the ring was the slowest part of a foreign stream */                           \
     "s_sub_u32 %[t0], %[op], %[dist]\n\t"                                                                              \
     "v_add_u32 %[vb], %[t0], %[lane]\n\t"                                                                              \
     "v_lshlrev_b32 %[vb], %[sh], %[vb]\n\t"                                                                            \
-    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
-    GL " %[vb], %[vb], %[outp]\n\t"                                                                                    \
     "s_add_u32 %[opb], %[opb], %[len]\n\t"                                                                             \
-    "s_waitcnt vmcnt(0)\n\t"                                                                                           \
-    WR " %[va], %[vb]\n\t"                                                                                             \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vd0], %[vb], %[outp]\n\t"                                                                                   \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
     "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
-    "s_cbranch_scc1 L_farmore_%=\n\t"                                                                                  \
-    "s_branch L_top_%=\n\t"                                                                                            \
-    "L_farmore_%=:\n\t"                                                                                                \
-    "s_mov_b32 %[t1], 64\n\t"                                                                                          \
-    "L_farloop_%=:\n\t"                                                                                                \
-    "s_sub_u32 %[t0], %[len], %[t1]\n\t"                                                                               \
+    "s_cbranch_scc0 L_farw_%=\n\t"                                                                                     \
+    "s_sub_u32 %[t0], %[len], 64\n\t"                                                                                  \
     "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
-    "s_add_u32 %[e], %[op], %[t1]\n\t"                                                                                 \
-    "s_sub_u32 %[t0], %[e], %[dist]\n\t"                                                                               \
-    "s_add_u32 %[e], %[e], %[a0]\n\t"                                                                                  \
-    "v_add_u32 %[vb], %[t0], %[lane]\n\t"                                                                              \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vd1], %[vb], %[outp] offset:%[o1]\n\t"                                                                      \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 128\n\t"                                                                                     \
+    "s_cbranch_scc0 L_farw_%=\n\t"                                                                                     \
+    "s_sub_u32 %[t0], %[len], 128\n\t"                                                                                 \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vd2], %[vb], %[outp] offset:%[o2]\n\t"                                                                      \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 192\n\t"                                                                                     \
+    "s_cbranch_scc0 L_farw_%=\n\t"                                                                                     \
+    "s_sub_u32 %[t0], %[len], 192\n\t"                                                                                 \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vd3], %[vb], %[outp] offset:%[o3]\n\t"                                                                      \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 256\n\t"                                                                                     \
+    "s_cbranch_scc0 L_farw_%=\n\t"                                                                                     \
+    "s_sub_u32 %[t0], %[len], 256\n\t"                                                                                 \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    GL " %[vd4], %[vb], %[outp] offset:%[o4]\n\t"                                                                      \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "L_farw_%=:\n\t"                                                                                                   \
+    "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"                                                                            \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                      \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    WR " %[va], %[vd0]\n\t"                                                                                            \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 64\n\t"                                                                                      \
+    "s_cbranch_scc0 L_top_%=\n\t"                                                                                      \
+    "s_sub_u32 %[t0], %[len], 64\n\t"                                                                                  \
+    "s_add_u32 %[e], %[e], 64\n\t"                                                                                     \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
     "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
-    "v_lshlrev_b32 %[vb], %[sh], %[vb]\n\t"                                                                            \
     "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
     "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
     "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
-    GL " %[vb], %[vb], %[outp]\n\t"                                                                                    \
-    "s_add_u32 %[t1], %[t1], 64\n\t"                                                                                   \
-    "s_waitcnt vmcnt(0)\n\t"                                                                                           \
-    WR " %[va], %[vb]\n\t"                                                                                             \
+    WR " %[va], %[vd1]\n\t"                                                                                            \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
-    "s_cmp_lt_u32 %[t1], %[len]\n\t"                                                                                   \
-    "s_cbranch_scc1 L_farloop_%=\n\t"                                                                                  \
+    "s_cmp_gt_u32 %[len], 128\n\t"                                                                                     \
+    "s_cbranch_scc0 L_top_%=\n\t"                                                                                      \
+    "s_sub_u32 %[t0], %[len], 128\n\t"                                                                                 \
+    "s_add_u32 %[e], %[e], 64\n\t"                                                                                     \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    WR " %[va], %[vd2]\n\t"                                                                                            \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 192\n\t"                                                                                     \
+    "s_cbranch_scc0 L_top_%=\n\t"                                                                                      \
+    "s_sub_u32 %[t0], %[len], 192\n\t"                                                                                 \
+    "s_add_u32 %[e], %[e], 64\n\t"                                                                                     \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    WR " %[va], %[vd3]\n\t"                                                                                            \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
+    "s_cmp_gt_u32 %[len], 256\n\t"                                                                                     \
+    "s_cbranch_scc0 L_top_%=\n\t"                                                                                      \
+    "s_sub_u32 %[t0], %[len], 256\n\t"                                                                                 \
+    "s_add_u32 %[e], %[e], 64\n\t"                                                                                     \
+    "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"                                                                             \
+    "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
+    "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
+    "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
+    WR " %[va], %[vd4]\n\t"                                                                                            \
+    "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
     "s_branch L_top_%=\n\t"                                                                                            \
     "L_before_%=:\n\t"                                                                                                 \
     BEFORE                                                                                                             \
@@ -841,7 +897,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             }
             uint32_t stage, len = 0, dist = 0;
             {
-                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, t2, ee, opx, va, vb, vr;
+                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, t2, ee, opx, va, vb, vr, vd0, vd1, vd2, vd3, vd4;
                 // no flush is due and the match fits `out` while op + len <= oplim (what service() would test)
                 const uint32_t fl = flushed + kFlushAt - 1u, oplim = out_cap < fl ? out_cap : fl;
                 const unsigned long long out_addr = (unsigned long long)(uintptr_t)J.out;
@@ -852,19 +908,23 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                     asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u8", "ds_write_b8", "global_load_ubyte", ZR_INFLATE_BEFORE_STREAM)
                                  : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
-                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr)
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr), [vd0] "=&v"(vd0), [vd1] "=&v"(vd1),
+                                   [vd2] "=&v"(vd2), [vd3] "=&v"(vd3), [vd4] "=&v"(vd4)
                                  : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(0),
-                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
+                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot), [o1] "n"(64 * sizeof(T)), [o2] "n"(128 * sizeof(T)),
+                                   [o3] "n"(192 * sizeof(T)), [o4] "n"(256 * sizeof(T))
                                  : "scc", "vcc", "memory", "s42", "s43", "s44", "s45");
                 } else {
                     asm volatile(ZR_INFLATE_FAST_LOOP("ds_read_u16", "ds_write_b16", "global_load_ushort", ZR_INFLATE_BEFORE_PART)
                                  : "+{s[40:41]}"(hold), [cnt] "+s"(cnt), [widx] "+s"(widx), [npend] "+s"(npend), [opb] "+s"(opb),
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
-                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr)
+                                   [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr), [vd0] "=&v"(vd0), [vd1] "=&v"(vd1),
+                                   [vd2] "=&v"(vd2), [vd3] "=&v"(vd3), [vd4] "=&v"(vd4)
                                  : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(1),
-                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot)
+                                   [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot), [o1] "n"(64 * sizeof(T)), [o2] "n"(128 * sizeof(T)),
+                                   [o3] "n"(192 * sizeof(T)), [o4] "n"(256 * sizeof(T))
                                  : "scc", "vcc", "memory", "s42", "s43", "s44", "s45");
                 }
 #ifdef ZR_INFLATE_STATS
