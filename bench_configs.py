@@ -90,9 +90,11 @@ def main():
         big = torch.randint(0, 256, ((max(sizes) << 20) + 16,), dtype=torch.uint8, device="cuda")
         out = torch.zeros(2, dtype=torch.int32, device="cuda")
         dst = torch.empty_like(big)
-        # the first kernels of a process run at idle clocks: ~0.5 s of streaming first (the 64 MiB Adler row measured
-        # 16.4 us as the first row of a fresh process, 11.4 us behind other work)
-        for _ in range(3000):
+        # the first kernels of a process run at idle clocks, and a process started within seconds of a heavy GPU job runs
+        # 4-5 % slow for about two seconds (bench.py, SETTLE_LAUNCHES): 2.5 s of streaming first.  (The 64 MiB rows are the
+        # first ones measured and the most sensitive: behind a 0.5 s settle they read 0.44-0.47 in passes that followed the
+        # bench's heavy legs and 0.61 in a pass of their own.)
+        for _ in range(15000):
             zr.adler32_crc32_dev(big, out, length=max(sizes) << 20)
         torch.cuda.synchronize()
         for mib in sizes:
