@@ -235,22 +235,27 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
 // of one wave execute in order, so a ds_read after a ds_write of the same bytes needs no wait.
 #define ZR_INFLATE_FAST_LOOP(RD, WR, GL, BEFORE)                                                                       \
     "s_mov_b32 s43, 0\n\t"                                                                                             \
+    /* Inside the loop the two counters the literal path tests live BIASED, so that the instruction that updates them    \
+       sets SCC and no compare is needed (the scalar unit is what sixteen streams per CU share): cnt as cnt - 32 (a       \
+       borrow = fewer than 32 bits left), npend as npend - 64 (a carry = the run is full), with opb + 64 and lane - 64   \
+       beside it.  The C++ around the statement converts. */                                                          \
     "L_top_%=:\n\t"                                                                                                    \
-    "s_cmp_gt_u32 %[cnt], 31\n\t"                                                                                      \
-    "s_cbranch_scc1 L_look_%=\n\t"                                                                                     \
+    "s_cmp_lt_i32 %[cnt], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 L_look_%=\n\t"                                                                                     \
+    "L_refill_%=:\n\t"                                                                                                 \
     "s_cmp_eq_u32 %[widx], 64\n\t"                                                                                     \
     "s_cbranch_scc1 L_exit0_%=\n\t"                                                                                    \
     "v_readlane_b32 s42, %[cur], %[widx]\n\t"                                                                          \
     "s_add_u32 %[widx], %[widx], 1\n\t"                                                                                \
-    "s_nop 0\n\t"                                                                                                      \
-    "s_lshl_b64 s[44:45], s[42:43], %[cnt]\n\t"                                                                        \
+    "s_add_u32 %[t0], %[cnt], 32\n\t"                                                                                  \
+    "s_lshl_b64 s[44:45], s[42:43], %[t0]\n\t"                                                                         \
     "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"                                                                        \
     "s_add_u32 %[cnt], %[cnt], 32\n\t"                                                                                 \
     "L_look_%=:\n\t"                                                                                                   \
-    "v_bfe_u32 %[va], s40, 0, %[litroot]\n\t"                                                                    \
+    "v_bfe_u32 %[va], s40, 0, %[litroot]\n\t"                                                                          \
     "v_lshl_add_u32 %[va], %[va], 1, %[litb]\n\t"                                                                      \
     "ds_read_u16 %[vb], %[va]\n\t"                                                                                     \
-    "v_cmp_eq_u32 vcc, %[npend], %[lane]\n\t"                                                                          \
+    "v_cmp_eq_u32 vcc, %[npend], %[laneb]\n\t"                                                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
     "v_readfirstlane_b32 %[e], %[vb]\n\t"                                                                              \
     "v_lshrrev_b32 %[vb], 4, %[vb]\n\t"                                                                                \
@@ -259,10 +264,13 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_and_b32 %[t0], %[e], 15\n\t"                                                                                    \
     "v_cndmask_b32 %[lit], %[lit], %[vb], vcc\n\t"                                                                     \
     "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
-    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
     "s_add_u32 %[npend], %[npend], 1\n\t"                                                                              \
-    "s_cmp_lg_u32 %[npend], 64\n\t"                                                                                    \
-    "s_cbranch_scc1 L_top_%=\n\t"                                                                                      \
+    "s_cbranch_scc1 L_full_%=\n\t"                                                                                     \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
+    "s_cbranch_scc0 L_look_%=\n\t"                                                                                     \
+    "s_branch L_refill_%=\n\t"                                                                                         \
+    "L_full_%=:\n\t"                                                                                                   \
+    "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
     "s_branch L_exit0_%=\n\t"                                                                                          \
     "L_notlit_%=:\n\t"                                                                                                 \
     /* e - 0x1010 = code length | (symbol - 257) << 4; symbols 257..285 only (256, 286.., the long and bad marks leave) */ \
@@ -291,14 +299,14 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_lshr_b64 s[40:41], s[40:41], %[t0]\n\t"                                                                         \
     "s_sub_u32 %[cnt], %[cnt], %[t0]\n\t"                                                                              \
     "L_havelen_%=:\n\t"                                                                                                \
-    "s_cmp_gt_u32 %[cnt], 31\n\t"                                                                                      \
-    "s_cbranch_scc1 L_dist_%=\n\t"                                                                                     \
+    "s_cmp_lt_i32 %[cnt], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 L_dist_%=\n\t"                                                                                     \
     "s_cmp_eq_u32 %[widx], 64\n\t"                                                                                     \
     "s_cbranch_scc1 L_exit1_%=\n\t"                                                                                    \
     "v_readlane_b32 s42, %[cur], %[widx]\n\t"                                                                          \
     "s_add_u32 %[widx], %[widx], 1\n\t"                                                                                \
-    "s_nop 0\n\t"                                                                                                      \
-    "s_lshl_b64 s[44:45], s[42:43], %[cnt]\n\t"                                                                        \
+    "s_add_u32 %[t0], %[cnt], 32\n\t"                                                                                  \
+    "s_lshl_b64 s[44:45], s[42:43], %[t0]\n\t"                                                                         \
     "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"                                                                        \
     "s_add_u32 %[cnt], %[cnt], 32\n\t"                                                                                 \
     "L_dist_%=:\n\t"                                                                                                   \
@@ -325,18 +333,18 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
     "s_cmp_gt_u32 %[t1], %[oplim]\n\t"                                                                                 \
     "s_cbranch_scc1 L_exit2_%=\n\t"                                                                                    \
     /* the waiting literals go to the ring: lane j < npend -> position opb + j */                                     \
-    "s_cmp_eq_u32 %[npend], 0\n\t"                                                                                     \
+    "s_cmp_eq_u32 %[npend], 0xffffffc0\n\t"                                                                             \
     "s_cbranch_scc1 L_copy_%=\n\t"                                                                                     \
-    "v_cmp_gt_u32 vcc, %[npend], %[lane]\n\t"                                                                             \
-    "s_add_u32 %[e], %[opb], %[a0]\n\t"                                                                                \
+    "v_cmp_gt_u32 vcc, %[npend], %[laneb]\n\t"                                                                          \
+    "s_add_u32 %[e], %[opb], %[a0m]\n\t"                                                                               \
     "v_add_u32 %[va], %[e], %[lane]\n\t"                                                                               \
     "v_and_b32 %[va], %[mask], %[va]\n\t"                                                                              \
     "v_lshl_add_u32 %[va], %[va], %[sh], %[ringb]\n\t"                                                                 \
     "s_and_saveexec_b64 s[44:45], vcc\n\t"                                                                             \
     WR " %[va], %[lit]\n\t"                                                                                            \
     "s_mov_b64 exec, s[44:45]\n\t"                                                                                     \
-    "s_mov_b32 %[opb], %[op]\n\t"                                                                                      \
-    "s_mov_b32 %[npend], 0\n\t"                                                                                        \
+    "s_add_u32 %[opb], %[op], 64\n\t"                                                                                   \
+    "s_mov_b32 %[npend], 0xffffffc0\n\t"                                                                               \
     "L_copy_%=:\n\t"                                                                                                   \
     /* destination: ring slot of op + lane, lanes below len */                                                        \
     "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"                                                                            \
@@ -897,10 +905,13 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             }
             uint32_t stage, len = 0, dist = 0;
             {
-                uint32_t widx = wnext - cbase, opb = op - npend, t0, t1, t2, ee, opx, va, vb, vr, vd0, vd1, vd2, vd3, vd4;
+                uint32_t widx = wnext - cbase, opb = op - npend + 64u, t0, t1, t2, ee, opx, va, vb, vr, vd0, vd1, vd2, vd3, vd4;
                 // no flush is due and the match fits `out` while op + len <= oplim (what service() would test)
                 const uint32_t fl = flushed + kFlushAt - 1u, oplim = out_cap < fl ? out_cap : fl;
                 const unsigned long long out_addr = (unsigned long long)(uintptr_t)J.out;
+                const uint32_t laneb = (uint32_t)lane - 64u;
+                cnt -= 32u;                                       // the loop's biased forms (ZR_INFLATE_FAST_LOOP)
+                npend -= 64u;
 #ifdef ZR_INFLATE_STATS
                 const unsigned long long zr_t0 = __builtin_readcyclecounter();
 #endif
@@ -910,7 +921,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
                                    [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr), [vd0] "=&v"(vd0), [vd1] "=&v"(vd1),
                                    [vd2] "=&v"(vd2), [vd3] "=&v"(vd3), [vd4] "=&v"(vd4)
-                                 : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
+                                 : [lane] "v"(lane), [laneb] "v"(laneb), [cur] "v"(cur), [a0] "s"(a0), [a0m] "s"(a0 - 64u), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(0),
                                    [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot), [o1] "n"(64 * sizeof(T)), [o2] "n"(128 * sizeof(T)),
                                    [o3] "n"(192 * sizeof(T)), [o4] "n"(256 * sizeof(T))
@@ -921,7 +932,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
                                    [lit] "+v"(litbuf), [reach] "+s"(reach), [stage] "=&s"(stage), [len] "=&s"(len), [dist] "=&s"(dist), [e] "=&s"(ee),
                                    [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [op] "=&s"(opx), [va] "=&v"(va), [vb] "=&v"(vb), [vr] "=&v"(vr), [vd0] "=&v"(vd0), [vd1] "=&v"(vd1),
                                    [vd2] "=&v"(vd2), [vd3] "=&v"(vd3), [vd4] "=&v"(vd4)
-                                 : [lane] "v"(lane), [cur] "v"(cur), [a0] "s"(a0), [oplim] "s"(oplim), [litb] "s"(lds_lit),
+                                 : [lane] "v"(lane), [laneb] "v"(laneb), [cur] "v"(cur), [a0] "s"(a0), [a0m] "s"(a0 - 64u), [oplim] "s"(oplim), [litb] "s"(lds_lit),
                                    [distb] "s"(lds_dist), [ringb] "s"(lds_ring), [outp] "s"(out_addr), [dictlen] "s"(dict_len), [near] "n"(kNear), [mask] "n"(M), [sh] "n"(1),
                                    [litroot] "n"(kLitRoot), [distroot] "n"(kDistRoot), [o1] "n"(64 * sizeof(T)), [o2] "n"(128 * sizeof(T)),
                                    [o3] "n"(192 * sizeof(T)), [o4] "n"(256 * sizeof(T))
@@ -930,6 +941,9 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
 #ifdef ZR_INFLATE_STATS
                 zr_tasm += __builtin_readcyclecounter() - zr_t0;
 #endif
+                cnt += 32u;
+                npend += 64u;
+                opb -= 64u;
                 wnext = cbase + widx;
                 if (widx == 64) {                                                     // the 64 fetched words are used up
                     cbase += 64;
