@@ -167,3 +167,45 @@ def test_mutated_large_streams_agree_with_the_oracle(mods):
         elif ost == -3:
             assert zr.rocm.lib().zng_rocm_last_error().decode() == omsg, (k, kind, at)
     assert regular >= 1                                    # some damage leaves a valid stream (a literal changed)
+
+
+def test_two_host_threads_on_two_streams(mods):
+    """scratch, candidate lists and part slots are keyed by the caller's HIP stream, the part counter is per thread: two
+    host threads inflating different large streams at once, several times over, each get their own bytes"""
+    import threading
+    torch, inf, dfl = mods
+    plains = [synth.silesia_like(24 << 20, seed=700 + k).tobytes() for k in range(2)]
+    comps = []
+    for k, p in enumerate(plains):
+        if k == 0:
+            comps.append(_raw(p, 6))                                         # a CPython stream
+        else:
+            d_plain = torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).cuda()
+            c, n = dfl.deflate_dev(d_plain, level=6)                         # and one of this library's own
+            comps.append(c[:n].cpu().numpy().tobytes())
+    srcs = [torch.from_numpy(np.frombuffer(c, dtype=np.uint8).copy()).cuda() for c in comps]
+    want = [torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).cuda() for p in plains]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            dst = torch.zeros(len(plains[k]) + 64, dtype=torch.uint8, device="cuda")
+            for rep in range(4):
+                dst.zero_()
+                torch.cuda.current_stream().synchronize()
+                st, n, used, parts = inf.inflate_large_dev(srcs[k], dst, stream=stream)
+                if (st, n, used) != (1, len(plains[k]), len(comps[k])) or parts < 8:
+                    errors.append((k, rep, st, n, used, parts))
+                elif not torch.equal(dst[:n], want[k]) or int(dst[n:].max()) != 0:
+                    errors.append((k, rep, "bytes differ"))
+        except Exception as e:                                               # noqa: BLE001 (reported below)
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
