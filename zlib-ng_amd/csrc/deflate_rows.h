@@ -252,7 +252,7 @@ struct RowsMatch {                      // per lane: what a batch carries from i
 __device__ __forceinline__ void rows_front(uint32_t n, uint32_t P, RowShared *sh, int t, bool refresh, RowsFront &f,
                                            uint32_t *cover_in) {
     const uint8_t *ring = sh->ring;
-    const int lane = t & 63;
+    [[maybe_unused]] const int lane = t & 63;            // (the stamps of the diagnostic build use it)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t p = P + (uint32_t)t;
     const uint32_t pi = p & (kRingBytes - 1u);
