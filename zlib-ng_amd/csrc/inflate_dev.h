@@ -27,6 +27,6 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
 
 // the parts of ONE large stream, 16-bit symbols out (inflate_large.hip); results: 8 words per part
 int launch_inflate_parts_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, const unsigned long long *d_starts,
-                                hipStream_t stream);
+                                bool many, hipStream_t stream);
 
 }  // namespace zr

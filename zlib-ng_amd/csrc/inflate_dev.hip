@@ -76,17 +76,59 @@ constexpr int kDistRootStream = 9, kDistRootPart = 8;
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 constexpr int kCodeLit = 0, kCodeDist = 1, kCodeCl = 2;
 
+// Whole streams, and the parts of a call with few of them: every table has its own place (9.9 KiB with a ring of bytes,
+// exactly 16 streams per CU; 12.9 KiB with a ring of 16-bit symbols, 12 parts per CU).
 template <int RING, typename T, int DR, int LR>
-struct InflateLds {
+struct InflateLdsStream {
     uint16_t lit[1 << LR];
     uint32_t dist[1 << DR];             // wide entries: code length | extra bits << 4 | base distance << 8 (wide_distance)
-    uint16_t cl[1 << kClRoot];
-    uint32_t cnt[3][16], first[3][16], offs[3][16], run[16];
-    uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[32];
+    uint16_t cl_[1 << kClRoot];
+    uint32_t cnt_[3][16], first_[3][16], offs_[3][16], run[16];
+    uint16_t sorted_lit[288], sorted_dist[32], sorted_cl_[32];
     uint8_t  lens[320 + 8];
-    uint8_t  cl_lens[24];
+    uint8_t  cl_lens_[24];
     T        ring[RING] __attribute__((aligned(16)));
+    __device__ __forceinline__ uint32_t *cnt(int which) { return cnt_[which]; }
+    __device__ __forceinline__ uint32_t *first(int which) { return first_[which]; }
+    __device__ __forceinline__ uint32_t *offs(int which) { return offs_[which]; }
+    __device__ __forceinline__ uint16_t *cl() { return cl_; }
+    __device__ __forceinline__ uint16_t *sorted_cl() { return sorted_cl_; }
+    __device__ __forceinline__ uint8_t *cl_lens() { return cl_lens_; }
 };
+// Parts, when there are many (16-bit symbols: the ring alone is 8 KiB): LDS is what limits how many decode at once, so
+// the layout is packed.
+// The code-length code -- root table, sorted symbols, counts, the 19 lengths -- only lives while a dynamic header is read,
+// and the distance table is only built when that is over: one place for both; the builder's first-code and offset words
+// are 16 bits.  12.2 KiB: a 13th part per CU (part kernel of the cfg3 stream 6.0 -> 5.25 ms).  (The same layout for
+// whole streams cost their kernel 5 % -- 42.1 -> 39.8 GB/s on the level-1 class's streams, with the LDS size padded
+// back to what it was -- so they keep theirs.)
+template <int RING, typename T, int DR, int LR>
+struct InflateLdsPart {
+    uint16_t lit[1 << LR];
+    union {
+        uint32_t dist[1 << DR];
+        struct {
+            uint16_t cl[1 << kClRoot];
+            uint16_t sorted_cl[32];
+            uint32_t cnt[16];
+            uint16_t first[16], offs[16];
+            uint8_t  cl_lens[24];
+        } h;
+    };
+    uint32_t cnt_[2][16];               // [code][length]; slot 0 of a code: its longest length
+    uint16_t first_[2][16], offs_[2][16], run[16];
+    uint16_t sorted_lit[288], sorted_dist[32];
+    uint8_t  lens[320 + 8];
+    T        ring[RING] __attribute__((aligned(16)));
+    __device__ __forceinline__ uint32_t *cnt(int which) { return which == kCodeCl ? h.cnt : cnt_[which]; }
+    __device__ __forceinline__ uint16_t *first(int which) { return which == kCodeCl ? h.first : first_[which]; }
+    __device__ __forceinline__ uint16_t *offs(int which) { return which == kCodeCl ? h.offs : offs_[which]; }
+    __device__ __forceinline__ uint16_t *cl() { return h.cl; }
+    __device__ __forceinline__ uint16_t *sorted_cl() { return h.sorted_cl; }
+    __device__ __forceinline__ uint8_t *cl_lens() { return h.cl_lens; }
+};
+static_assert(sizeof(((InflateLdsPart<4096, uint16_t, 8, 10> *)nullptr)->h) <= sizeof(uint32_t) << 8, "the header's tables must fit the distance table's place");
+
 
 // base values / extra bits of the length and distance symbols (RFC 1951 3.2.5; inftrees.c:38-49 hold the same numbers)
 __device__ __forceinline__ void length_of(uint32_t k, uint32_t *base, uint32_t *extra) {     // k = symbol - 257, 0..28
@@ -130,7 +172,9 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 template <typename LDS>
 __device__ __forceinline__ int build_code(LDS &L, int which, const uint8_t *lens, int n, int root, uint16_t *table,
                           uint16_t *sorted, int lane) {
-    uint32_t *cnt = L.cnt[which], *first = L.first[which], *offs = L.offs[which];
+    auto *cnt = L.cnt(which);
+    auto *first = L.first(which);
+    auto *offs = L.offs(which);
     if (lane < 16) cnt[lane] = 0;
     wave_sync();
     for (int s = lane; s < n; s += 64) atomicAdd(&cnt[ZR_IDX(lens[s], 16)], 1u);
@@ -144,9 +188,9 @@ __device__ __forceinline__ int build_code(LDS &L, int which, const uint8_t *lens
         left = (left << 1) - (int)c;
         if (left < 0) over = true;
         if (lane == 0) {
-            first[len] = code;
-            offs[len] = off;
-            L.run[len] = off;
+            first[len] = (std::remove_reference_t<decltype(first[0])>)code;      // (< 2^len for every set that is not rejected)
+            offs[len] = (std::remove_reference_t<decltype(offs[0])>)off;
+            L.run[len] = (std::remove_reference_t<decltype(L.run[0])>)off;
         }
         code = (code + c) << 1;
         off += c;
@@ -174,7 +218,7 @@ __device__ __forceinline__ int build_code(LDS &L, int which, const uint8_t *lens
             const unsigned long long same = __ballot(hit);
             const uint32_t at = uni(L.run[ZR_IDX(lu, 16)]);
             if (hit) sorted[ZR_IDX(at + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)), which == kCodeLit ? 288 : 32)] = (uint16_t)s;
-            if (lane == f) L.run[ZR_IDX(lu, 16)] = at + (uint32_t)__builtin_popcountll(same);
+            if (lane == f) L.run[ZR_IDX(lu, 16)] = (std::remove_reference_t<decltype(L.run[0])>)(at + (uint32_t)__builtin_popcountll(same));
             active = active && !hit;
             m &= ~same;
             wave_sync();
@@ -204,10 +248,10 @@ template <typename LDS>
 __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const uint16_t *sorted,
                                               unsigned long long hold) {
     const uint32_t rev15 = __builtin_bitreverse32((uint32_t)hold & 0x7fffu) >> 17;
-    const int max = (int)uni(L.cnt[which][0]);
+    const int max = (int)uni(L.cnt(which)[0]);
     for (int len = root + 1; len <= max; ++len) {
-        const uint32_t d = (rev15 >> (15 - len)) - uni(L.first[which][len]);
-        if (d < uni(L.cnt[which][len])) return make_entry((uint32_t)len, uni(sorted[ZR_IDX(uni(L.offs[which][len]) + d, which == kCodeLit ? 288 : 32)]));
+        const uint32_t d = (rev15 >> (15 - len)) - uni(L.first(which)[len]);
+        if (d < uni(L.cnt(which)[len])) return make_entry((uint32_t)len, uni(sorted[ZR_IDX(uni(L.offs(which)[len]) + d, which == kCodeLit ? 288 : 32)]));
     }
     return kBadMark;
 }
@@ -606,7 +650,7 @@ __device__ __forceinline__ uint32_t long_code(LDS &L, int which, int root, const
 // unresolved references propagate by themselves, and the context chain of inflate_resolve.hip turns them into bytes.
 // Results per part: 8 words {symbols produced, end bit (lo, hi), status, message, furthest reach in front of the part,
 // index of the start it ended on, BFINAL seen}.
-template <int RING, bool PART>
+template <int RING, bool PART, bool COMPACT = false>
 __global__ __launch_bounds__(64)
 void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njobs, uint32_t *__restrict__ results,
                             const unsigned long long *__restrict__ starts) {
@@ -620,7 +664,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     static_assert(kFlushAt + 16 + kStoredPiece + 258 <= RING - 258, "ring too small for the flush / stored-chunk sizes");
     static_assert(kFlushAt + 258 < kNear, "a source beyond kNear must have left the ring (the fast loop reads it from HBM)");
     constexpr int kDistRoot = PART ? kDistRootPart : kDistRootStream, kLitRoot = PART ? kLitRootPart : kLitRootStream;
-    __shared__ InflateLds<RING, T, kDistRoot, kLitRoot> L;
+    __shared__ typename std::conditional<COMPACT, InflateLdsPart<RING, T, kDistRoot, kLitRoot>, InflateLdsStream<RING, T, kDistRoot, kLitRoot>>::type L;
     const int lane = threadIdx.x;
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
@@ -834,20 +878,20 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
             hold >>= 14;
             cnt -= 14;
             if (nlen > 286 || ndist > 30) { msg = kMsgTooMany; break; }
-            if (lane < 19) L.cl_lens[lane] = 0;
+            if (lane < 19) L.cl_lens()[lane] = 0;
             wave_sync();
             for (uint32_t i = 0; i < ncode; ++i) {
                 if (cnt < 32) append();
-                if (lane == 0) L.cl_lens[kClOrder[i]] = (uint8_t)(hold & 7u);
+                if (lane == 0) L.cl_lens()[kClOrder[i]] = (uint8_t)(hold & 7u);
                 hold >>= 3;
                 cnt -= 3;
             }
             wave_sync();
-            if (uni((uint32_t)build_code(L, kCodeCl, L.cl_lens, 19, kClRoot, L.cl, L.sorted_cl, lane))) { msg = kMsgCodeLengthsSet; break; }
+            if (uni((uint32_t)build_code(L, kCodeCl, L.cl_lens(), 19, kClRoot, L.cl(), L.sorted_cl(), lane))) { msg = kMsgCodeLengthsSet; break; }
             uint32_t have = 0;
             while (have < nlen + ndist) {
                 if (cnt < 32) append();
-                const uint32_t e = uni(L.cl[(uint32_t)hold & ((1u << kClRoot) - 1u)]);
+                const uint32_t e = uni(L.cl()[(uint32_t)hold & ((1u << kClRoot) - 1u)]);
                 // an empty code-length code yields one-bit entries of value 0: each reads as length 0
                 // (inftrees.c:114-122 + inflate.c:846-849)
                 const uint32_t nb = e & 15u, sym = e >> 4;
@@ -1123,10 +1167,17 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
 }
 
 // the parts of ONE large stream (inflate_large.hip): d_starts = sorted start bits, one per job; results: 8 words per part
+// `many`: more parts of real work than a chip holds at 12 per CU -- then the packed LDS layout (InflateLdsPart: 13 per CU)
+// decodes more symbols per second (the cfg3 stream of this library's level-6 class: 8.2 -> 7.4 ms).  With fewer parts the
+// call lasts as long as its longest part, and a part is faster in the plain layout among 12 (a CPython stream: 12.4
+// against 13.2 ms): two instantiations, chosen per call.
 int launch_inflate_parts_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, const unsigned long long *d_starts,
-                                hipStream_t st) {
+                                bool many, hipStream_t st) {
     if (!njobs) return ZNG_ROCM_OK;
-    ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, true>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
+    if (many)
+        ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, true, true>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
+    else
+        ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, true, false>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
     ZR_HIP(hipGetLastError());
     return ZNG_ROCM_OK;
 }

@@ -129,7 +129,7 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
                 const uint32_t len16 = (uint32_t)(lo >> 8) & 0xffffu, nlen16 = (uint32_t)(lo >> 24) & 0xffffu;
                 if (((uint32_t)lo & 0xfeu) == 0u && len16 != 0u && (len16 ^ nlen16) == 0xffffu && b + 5 + len16 <= src_len) {
                     const uint32_t i = atomicAdd(&nlocal, 1u);
-                    if (i < kFindLocal) local[i] = (8ull * b) | (1ull << 63);
+                    if (i < kFindLocal) local[i] = (8ull * b) | (3ull << 62);          // bit 62: a stored block (light work)
                 }
             }
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ void validate_one(const uint8_t *__restrict__ src, unsigned long long
                              unsigned long long *__restrict__ good, uint32_t *__restrict__ ngood, uint32_t cap) {
     auto accept = [&]() {
         const uint32_t at = atomicAdd(ngood, 1u);
-        if (at < cap) good[at] = c0 & ~(1ull << 63);
+        if (at < cap) good[at] = c0 & ~(1ull << 63);      // (bit 62, "a stored block", stays)
     };
     if (c0 >> 63) {                                       // behind a marker: taken as it is
         accept();
@@ -412,9 +412,10 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     if (patterns_do) {
         good.resize(n12[1]);
         for (unsigned long long &b : good) b &= ~(1ull << 63);
-        std::sort(good.begin(), good.end());
+        std::sort(good.begin(), good.end(), [](unsigned long long x, unsigned long long y) { return (x & ~(1ull << 62)) < (y & ~(1ull << 62)); });
         unsigned long long prev = 0;
-        for (unsigned long long b : good) {
+        for (unsigned long long b62 : good) {
+            const unsigned long long b = b62 & ~(1ull << 62);
             if (b - prev > 8ull * (128u << 10)) patterns_do = false;
             prev = b;
         }
@@ -442,13 +443,20 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
         ZR_HIP(hipStreamSynchronize(st));
     }
     for (unsigned long long &b : good) b &= ~(1ull << 63);           // (the patterns pass leaves its "taken as it is" flag on)
-    std::sort(good.begin(), good.end());
+    std::sort(good.begin(), good.end(), [](unsigned long long x, unsigned long long y) { return (x & ~(1ull << 62)) < (y & ~(1ull << 62)); });
     std::vector<unsigned long long> starts;
     starts.push_back(0);
     const unsigned long long spacing = good.size() > kPartsUnthinned ? 8ull * kSpacingBytes : 1ull;
-    for (unsigned long long b : good)
-        if (b >= starts.back() + spacing && (b >> 3) + 16 < src_len) starts.push_back(b);
+    size_t heavy = 1;                                     // parts that are not a stored block: the ones that take time
+    for (unsigned long long b62 : good) {
+        const unsigned long long b = b62 & ~(1ull << 62);
+        if (b >= starts.back() + spacing && (b >> 3) + 16 < src_len) {
+            starts.push_back(b);
+            heavy += !(b62 >> 62);
+        }
+    }
     const size_t np = starts.size();
+    const bool many = heavy > 12u * (size_t)ctx()->cus;
     if (np < 4) return why("fewer than four block starts found");
 
     // ---- parts ----------------------------------------------------------------------------------------------------
@@ -475,7 +483,7 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
                                 i == 0 ? window_len : 32768u, 0u};
     ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
     ZR_HIP(hipMemcpyAsync(d_starts, starts.data(), np * 8, hipMemcpyHostToDevice, st));
-    if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, st)) return rc;
+    if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, many, st)) return rc;
     std::vector<uint32_t> res(np * 8);
     ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
@@ -506,7 +514,7 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
                 at += capi;
             }
             ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
-            if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, st)) return rc;
+            if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, many, st)) return rc;
             ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
             ZR_HIP(hipStreamSynchronize(st));
         }
