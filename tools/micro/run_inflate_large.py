@@ -47,7 +47,15 @@ if os.environ.get("ZR_STATS_LIB"):
     print("part durations (Mticks): min %.2f p10 %.2f median %.2f p90 %.2f p99 %.2f max %.2f; sum %.0f" % (*(q / 1e6), dur.sum() / 1e6))
     nbits = np.diff(np.append(stt, src.numel() * 8))
     order = np.argsort(-dur)
-    print("slowest parts: index, Mticks, symbols produced, compressed bytes to the next start, ticks per symbol, message")
+    t0 = a[:, 0].min(); span = a[:, 1].max() - t0
+    print("the launch: first start to last end %.2f Mticks; parts starting in the first 5 %% of it: %d; the last part to START does so at %.2f"
+          % (span / 1e6, int((a[:, 0] - t0 < 0.05 * span).sum()), (a[:, 0].max() - t0) / 1e6))
+    print("slowest parts: index, Mticks, symbols produced, compressed bytes to the next start, ticks per symbol, message, start and end in the launch (Mticks)")
     for j in order[:8]:
-        print("  %5d %7.2f %8d %8d %7.0f %d" % (j, dur[j] / 1e6, rs[j, 0], nbits[j] // 8, dur[j] / max(1, rs[j, 0]), rs[j, 4]))
+        print("  %5d %7.2f %8d %8d %7.0f %d  %6.2f %6.2f" % (j, dur[j] / 1e6, rs[j, 0], nbits[j] // 8, dur[j] / max(1, rs[j, 0]), rs[j, 4],
+                                                  (a[j, 0] - t0) / 1e6, (a[j, 1] - t0) / 1e6))
+    last = np.argsort(-a[:, 1])[:8]
+    print("last parts to END: index, start, end, symbols")
+    for j in last:
+        print("  %5d %6.2f %6.2f %8d" % (j, (a[j, 0] - t0) / 1e6, (a[j, 1] - t0) / 1e6, rs[j, 0]))
     print("median part: %d symbols, %d compressed bytes, %.0f ticks per symbol" % (np.median(rs[:, 0]), np.median(nbits) // 8, np.median(dur / np.maximum(1, rs[:, 0]))))

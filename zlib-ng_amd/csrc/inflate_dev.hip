@@ -658,6 +658,7 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
     constexpr uint32_t E = 16u / (uint32_t)sizeof(T);   // elements per 16-byte store
     constexpr uint32_t M = RING - 1;
     constexpr uint32_t kFlushAt = RING >= 4096 ? RING / 2 : RING / 4;   // unflushed bytes that trigger a flush
+    constexpr uint32_t kPrioStep = 128u << 10;                          // part mode: symbols produced per step of wave priority
     constexpr uint32_t kStoredPiece = RING >= 4096 ? 1024u : RING / 4;  // a stored block enters the ring in pieces of this
     constexpr uint32_t kNear = RING - 258;               // a source this close is still in the ring while the match is written
     // bytes not yet flushed never exceed kFlushAt + 16 + max(258, kStoredPiece); a match of 258 more must not overwrite them
@@ -760,6 +761,14 @@ void inflate_streams_kernel(const InflateJobDev *__restrict__ jobs, uint32_t njo
         // a later far match may read these bytes back from HBM: have the stores acknowledged first
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0);
+        if constexpr (PART) {
+            // A call lasts as long as its longest part, and a part that has produced several times what the others do (a
+            // block of long copies: 1.4 M symbols from 28 KB) is that part: it gets its instructions issued in front of the
+            // waves it shares a SIMD with (tools/micro/copy_cost.py: a copy costs a lone wave 0.49 us, one among twelve 0.66).
+            if (flushed >= kPrioStep * 3u) __builtin_amdgcn_s_setprio(3);
+            else if (flushed >= kPrioStep * 2u) __builtin_amdgcn_s_setprio(2);
+            else if (flushed >= kPrioStep) __builtin_amdgcn_s_setprio(1);
+        }
     };
     // Everything that is not decoding happens when the literal run is written out, i.e. once per match or per 64
     // literals: the run goes to the ring (clipped at out_cap: a run may have decoded past it), a flush when one is due,
