@@ -398,6 +398,9 @@ int zng_rocm_inflate_raw_threads(const uint8_t *src, size_t src_len, const uint8
     if ((!src && src_len) || window_len > 32768u || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
     DeviceGuard dev;
     const unsigned t = nthreads > 0 ? (unsigned)nthreads : zr_default_threads();
+    // one thread: nothing to cut the stream for -- the one-shot path (which takes a stream of 4 MiB and more up to the device
+    // and decodes it there, inflate_large.hip; a shorter one on this thread)
+    if (t == 1) return zng_rocm_inflate_raw_window(src, src_len, d_window, window_len, d_dst, dst_cap, out_len, in_used, nullptr);
     Engine *e = acquire_engine();
     if (!e) return ZNG_ROCM_EHIP;
     const size_t max_parts = 8u * (size_t)t;

@@ -145,24 +145,51 @@ void inflate_segments_kernel(const uint32_t *__restrict__ tokens, const uint8_t 
 //           those are then plain bytes.
 // K3 finishes the rest: a tail symbol needs one lookup in its group's base, any other symbol one lookup in the
 // previous segment's tail plus, when that is still a reference, one in that tail's base.
-// Each lane owns 32 symbols of the 32 KiB; all its loads are issued before any is used, so one step costs a
-// few memory round trips instead of 32 dependent ones.
+// Each lane owns 32 symbols of the 32 KiB.
 constexpr size_t kGroup = 64;
 
-__device__ __forceinline__ void tail_step(uint16_t *__restrict__ sym, long long cur_end, long long prev_end) {
-    constexpr int PER = (int)(kCtx / 1024);            // 32
-    uint16_t v[PER];
-    uint16_t *cur = sym + (cur_end - kCtx);
-    const uint16_t *prev = sym + (prev_end - kCtx);
+// A run of tail steps in which every step's `prev` is the step before's `cur` (both passes are such runs): the tail just
+// rewritten stays in LDS (two buffers of 64 KiB, one barrier per step) and the next tail to rewrite is already on its way
+// from HBM while this one is resolved -- a step is an LDS gather instead of three dependent trips to memory
+// (the 6500 segments of a 256 MiB stream: pass A 0.69 -> 0.33 ms, pass B 0.21 -> 0.18 ms).  step(i) = symbol index where the i-th tail ENDS.
+template <typename EndOf>
+__device__ __forceinline__ void tail_run(uint16_t *__restrict__ sym, long long prev_end, size_t nsteps, EndOf end_of) {
+    constexpr int PER = (int)(kCtx / 1024);            // 32 symbols per lane: symbol threadIdx.x + 1024 * k of the tail
+    __shared__ uint16_t tails[2][kCtx];
+    if (!nsteps) return;
+    uint16_t v[PER], nx[PER];
+    {
+        const uint16_t *prev = sym + (prev_end - kCtx);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) v[k] = cur[threadIdx.x + 1024 * k];
+        for (int k = 0; k < PER; ++k) nx[k] = prev[threadIdx.x + 1024 * k];
+        const uint16_t *cur = sym + (end_of(0) - kCtx);
 #pragma unroll
-    for (int k = 0; k < PER; ++k)
-        if (v[k] >= 256) v[k] = prev[v[k] - 256];
+        for (int k = 0; k < PER; ++k) v[k] = cur[threadIdx.x + 1024 * k];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) cur[threadIdx.x + 1024 * k] = v[k];
-    __threadfence_block();
+        for (int k = 0; k < PER; ++k) tails[0][threadIdx.x + 1024 * k] = nx[k];
+    }
     __syncthreads();
+    int b = 0;
+    for (size_t i = 0; i < nsteps; ++i) {
+        uint16_t *cur = sym + (end_of(i) - kCtx);
+        if (i + 1 < nsteps) {
+            const uint16_t *next = sym + (end_of(i + 1) - kCtx);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) nx[k] = next[threadIdx.x + 1024 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (v[k] >= 256) v[k] = tails[b][v[k] - 256];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            cur[threadIdx.x + 1024 * k] = v[k];
+            tails[b ^ 1][threadIdx.x + 1024 * k] = v[k];
+        }
+        __syncthreads();
+        b ^= 1;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = nx[k];
+    }
 }
 
 // grid.x = group.  Tails exist for segments 0 .. nsegs-2.  With a prior window (the 32768 symbols in front of
@@ -173,19 +200,22 @@ void inflate_context_group_kernel(const uint64_t *__restrict__ segs, size_t nseg
     const size_t first = (size_t)blockIdx.x * kGroup;
     size_t last = first + kGroup;
     if (last > nsegs - 1) last = nsegs - 1;
-    if (has_window && blockIdx.x == 0 && last > 0) tail_step(sym, (long long)segs[4], (long long)segs[1]);
-    for (size_t s = first + 1; s < last; ++s)
-        tail_step(sym, (long long)segs[3 * s + 4], (long long)segs[3 * s + 1]);
+    // tails first+1 .. last-1, each against the one before it; group 0 with a window starts one earlier: tail 0 against the window
+    const size_t s0 = (has_window && blockIdx.x == 0) ? first : first + 1;
+    if (s0 >= last) return;
+    tail_run(sym, (long long)segs[3 * s0 + 1], last - s0, [&](size_t i) { return (long long)segs[3 * (s0 + i) + 4]; });
 }
 
 // one workgroup; group g >= 1: its last tail against the last tail of group g-1
 __global__ __launch_bounds__(1024)
 void inflate_context_chain_kernel(const uint64_t *__restrict__ segs, size_t nsegs, uint16_t *__restrict__ sym) {
-    for (size_t first = kGroup; first < nsegs - 1; first += kGroup) {
-        size_t last = first + kGroup;
+    if (nsegs - 1 <= kGroup) return;
+    const size_t ngroups = (nsegs - 1 + kGroup - 1) / kGroup;
+    tail_run(sym, (long long)segs[3 * kGroup + 1], ngroups - 1, [&](size_t i) {
+        size_t last = (i + 2) * kGroup;
         if (last > nsegs - 1) last = nsegs - 1;
-        tail_step(sym, (long long)segs[3 * (last - 1) + 4], (long long)segs[3 * first + 1]);
-    }
+        return (long long)segs[3 * (last - 1) + 4];
+    });
 }
 
 // the symbols in front of sym[0]: the caller's window, right-aligned to the stream's first byte (zeros before it)
