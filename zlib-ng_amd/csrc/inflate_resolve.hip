@@ -257,6 +257,7 @@ void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, c
     const uint16_t *base_own = sym + ((long long)segs[3 * gs + 1] - kCtx);
     const size_t gp = s ? ((s - 1) / kGroup) * kGroup : 0;          // ... and of the previous segment's
     const uint16_t *base_prev = sym + ((long long)segs[3 * gp + 1] - kCtx);
+    const long long prev_off = prev - sym, own_off = base_own - sym, bprev_off = base_prev - sym;   // the same as offsets into sym
     auto resolve = [&](uint32_t v, long long i) -> uint32_t {
         if (v >= 256u) {
             if (i >= tail) {
@@ -279,13 +280,47 @@ void inflate_translate_kernel(const uint64_t *__restrict__ segs, size_t nsegs, c
     for (long long c = threadIdx.x; c < chunks; c += blockDim.x) {
         const long long i = a0 + 8 * c;
         const uint4 q = *reinterpret_cast<const uint4 *>(sym + i);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-        uint32_t lo = 0, hi = 0;
+        uint32_t lo, hi;
+        // References come in stretches (behind a part's start) and most wavefronts see none: those pack the low bytes of
+        // their eight symbols with two byte permutes (unpacking, testing and packing symbol by symbol was ~150 vector
+        // instructions per 8 symbols and the kernel ran at 1.7 TB/s whatever the data).
+        if (!__any(((q.x | q.y | q.z | q.w) & 0xff00ff00u) != 0u)) {
+            lo = __builtin_amdgcn_perm(q.y, q.x, 0x06040200u);
+            hi = __builtin_amdgcn_perm(q.w, q.z, 0x06040200u);
+        } else {
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t v = resolve((w[k >> 1] >> (16 * (k & 1))) & 0xffffu, i + k);
-            if (k < 4) lo |= (v & 0xffu) << (8 * k);
-            else hi |= (v & 0xffu) << (8 * (k - 4));
+            for (int k = 0; k < 8; ++k) v[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            // the lookups of all eight symbols are issued TOGETHER, unconditionally: inside their `if`s they were eight
+            // dependent trips to L2 one after the other
+            uint16_t g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long long tab = i + k >= tail ? own_off : prev_off;      // (a table may not exist where nothing names it:
+                g[k] = sym[v[k] >= 256u ? tab + (long long)(v[k] - 256u) : i + k];  //  a symbol that needs no lookup reads itself again)
+            }
+            bool again = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (v[k] >= 256u) {
+                    v[k] = g[k];
+                    again |= i + k < tail && v[k] >= 256u;
+                }
+            }
+            if (__any(again)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = sym[(i + k < tail && v[k] >= 256u) ? bprev_off + (long long)(v[k] - 256u) : i + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (i + k < tail && v[k] >= 256u) v[k] = g[k];
+            }
+            lo = hi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < 4) lo |= (v[k] & 0xffu) << (8 * k);
+                else hi |= (v[k] & 0xffu) << (8 * (k - 4));
+            }
         }
         uint8_t *d = out + i;
         if ((((uintptr_t)d) & 7u) == 0) {
