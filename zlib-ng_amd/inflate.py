@@ -75,12 +75,12 @@ def resolve_dev(dec, stream=None):
 
 
 def inflate_raw(src, dst, stream=None):
-    """one-shot: host bytes in, plaintext into the CUDA tensor `dst`; returns (zlib status, bytes produced)"""
+    """one-shot: host bytes (or a HostStream, which saves the Python copy) in, plaintext into the CUDA tensor `dst`;
+    returns (zlib status, bytes produced)"""
     rocm._need_init()
-    raw = bytes(src)
-    buf = C.create_string_buffer(raw, max(len(raw), 1))
+    hs = src if isinstance(src, HostStream) else HostStream(src)
     produced = C.c_uint64(0)
-    rc = rocm.lib().zng_rocm_inflate_raw(C.addressof(buf), len(raw), rocm._dev_ptr(dst), dst.numel(),
+    rc = rocm.lib().zng_rocm_inflate_raw(C.addressof(hs.buf), hs.n, rocm._dev_ptr(dst), dst.numel(),
                                          C.byref(produced), rocm._stream_ptr(stream))
     return rc, produced.value
 
