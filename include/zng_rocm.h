@@ -363,7 +363,8 @@ int  zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8
  * reference's.  Returns as zng_rocm_inflate_raw_window; synchronous. */
 int  zng_rocm_inflate_large_dev(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len,
                                 uint8_t *d_dst, size_t dst_cap, uint64_t *out_len, size_t *in_used, void *stream);
-/* parts on the chain of the calling thread's last zng_rocm_inflate_large_dev (0: the sequential decoder did it) */
+/* parts on the chain of the calling thread's last zng_rocm_inflate_large_dev or zng_rocm_inflate_raw* call (0: the
+ * sequential decoder did it) */
 int  zng_rocm_inflate_large_last_parts(void);
 
 /* Many independent raw streams at once: `nthreads` host threads (<= 0: as many as the host gives us) take the jobs in

@@ -599,6 +599,8 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     return 1;
 }
 
+void inflate_large_forget_parts() { t_large_parts = 0; }
+
 // A large stream that is in HOST memory (zng_rocm_inflate_raw*, and with them uncompress2 and the gzip / zlib one-shots):
 // up over PCIe once and through the device path; 0 = not done here (the caller's sequential decoder takes it).
 int inflate_large_from_host(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
@@ -625,6 +627,7 @@ int inflate_large_from_host(const uint8_t *src, size_t src_len, const uint8_t *d
 // negatives = errors.
 int inflate_large_device_only(const uint8_t *d_src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
                               size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st) {
+    t_large_parts = 0;
     Workspace *ws = workspace_for(st);
     if (!ws) return ZNG_ROCM_ENOMEM;
     std::lock_guard<std::mutex> use(ws->mu);

@@ -23,6 +23,7 @@ constexpr long long kCtx = 32768;        // MAX_WBITS 15: a distance never excee
 constexpr size_t kLargeHostStream = 4u << 20;   // compressed bytes from which a host-resident stream is decoded on the device
 int inflate_large_from_host(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
                             size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st);      // inflate_large.hip
+void inflate_large_forget_parts();       // the part counter of the calling thread back to 0 ("the sequential decoder did it")
 int inflate_raw_window_sequential(const uint8_t *src, size_t src_len, const uint8_t *d_window, uint32_t window_len, uint8_t *d_dst,
                                   size_t dst_cap, uint64_t *out_len, size_t *in_used, hipStream_t st);
 
@@ -524,6 +525,7 @@ int zng_rocm_inflate_raw_window(const uint8_t *src, size_t src_len, const uint8_
     DeviceGuard dev;
     if (window_len > (uint32_t)kCtx || (window_len && !d_window)) return ZNG_ROCM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    inflate_large_forget_parts();
     // a large stream goes up whole and is decoded on the device (inflate_large.hip: ~20 GB/s of output against 0.8 on
     // this thread); anything but a clean end of stream or a too-small destination is decoded again by the sequential
     // decoder, so status, message and byte counts are its
