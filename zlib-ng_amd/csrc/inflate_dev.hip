@@ -1183,6 +1183,17 @@ int launch_inflate_streams_device(const InflateJobDev *d_jobs, size_t njobs, uin
 int launch_inflate_parts_device(const InflateJobDev *d_jobs, size_t njobs, uint32_t *d_results, const unsigned long long *d_starts,
                                 bool many, hipStream_t st) {
     if (!njobs) return ZNG_ROCM_OK;
+#ifdef ZR_MEASURE_FORMS
+    static const int ring = [] {
+        const char *r = getenv("ZNG_ROCM_PART_RING");
+        return r ? atoi(r) : 4096;
+    }();
+    if (ring == 2048 && many) {
+        ZR_LAUNCH_TRACED((inflate_streams_kernel<2048, true, true>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
+        ZR_HIP(hipGetLastError());
+        return ZNG_ROCM_OK;
+    }
+#endif
     if (many)
         ZR_LAUNCH_TRACED((inflate_streams_kernel<4096, true, true>), dim3((unsigned)njobs), dim3(64), st, d_jobs, (uint32_t)njobs, d_results, d_starts);
     else

@@ -420,7 +420,7 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
             prev = b;
         }
         if (8ull * src_len - prev > 8ull * (128u << 10)) patterns_do = false;
-        good.resize(first);
+        if (!patterns_do) good.resize(first);
     }
     if (!patterns_do) {
         ZR_HIP(hipMemsetAsync(d_n, 0, 8, st));
@@ -442,8 +442,10 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
         ZR_HIP(hipMemcpyAsync(good.data() + first, d_good + first, (size_t)(n2 - first) * 8, hipMemcpyDeviceToHost, st));
         ZR_HIP(hipStreamSynchronize(st));
     }
-    for (unsigned long long &b : good) b &= ~(1ull << 63);           // (the patterns pass leaves its "taken as it is" flag on)
-    std::sort(good.begin(), good.end(), [](unsigned long long x, unsigned long long y) { return (x & ~(1ull << 62)) < (y & ~(1ull << 62)); });
+    if (!patterns_do) {                                              // (the patterns' list has been sorted above)
+        for (unsigned long long &b : good) b &= ~(1ull << 63);
+        std::sort(good.begin(), good.end(), [](unsigned long long x, unsigned long long y) { return (x & ~(1ull << 62)) < (y & ~(1ull << 62)); });
+    }
     std::vector<unsigned long long> starts;
     starts.push_back(0);
     const unsigned long long spacing = good.size() > kPartsUnthinned ? 8ull * kSpacingBytes : 1ull;
