@@ -102,6 +102,56 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
     };
     const unsigned long long per = (src_len + gridDim.x - 1) / gridDim.x;
     const unsigned long long lo_b = per * blockIdx.x, hi_b = lo_b + per < src_len ? lo_b + per : src_len;
+    if constexpr (PATTERNS) {
+        // the two byte patterns alone: a lane takes 16 byte positions from one 24-byte window (position by position, with a
+        // 16-byte load each, the pass read every byte 16 times and ran at 0.44 TB/s: 0.22 ms for 96 MB)
+        auto test = [&](unsigned long long w, unsigned long long b) {      // w: the 8 bytes at position b
+            if (b >= hi_b || b + 8 >= src_len) return;
+            if ((uint32_t)w == 0xffff0000u && b + 6 <= src_len) {
+                const uint32_t i = atomicAdd(&nlocal, 1u);
+                if (i < kFindLocal) local[i] = (8ull * (b + 4)) | (1ull << 63);
+            }
+            const uint32_t len16 = (uint32_t)(w >> 8) & 0xffffu, nlen16 = (uint32_t)(w >> 24) & 0xffffu;
+            if (((uint32_t)w & 0xfeu) == 0u && len16 != 0u && (len16 ^ nlen16) == 0xffffu && b + 5 + len16 <= src_len) {
+                const uint32_t i = atomicAdd(&nlocal, 1u);
+                if (i < kFindLocal) local[i] = (8ull * b) | (3ull << 62);
+            }
+        };
+        for (unsigned long long base = lo_b; base < hi_b; base += 4096) {
+            const unsigned long long b0 = base + 16ull * threadIdx.x;
+            if (b0 < hi_b) {
+                unsigned long long lo = 0, hi = 0, nx = 0;
+                if (b0 + 24 <= src_len) {
+                    const u32x4_unaligned v = load_u128(src + b0);
+                    lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+                    hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+                    const u32x4_unaligned n = load_u128(src + b0 + 8);                   // bytes 8 .. 23: the upper half is what is new
+                    nx = (unsigned long long)n.z | ((unsigned long long)n.w << 32);
+                } else {
+                    for (unsigned k = 0; k < 24 && b0 + k < src_len; ++k) {
+                        const unsigned long long x = load_u8(src + b0 + k);
+                        if (k < 8) lo |= x << (8 * k);
+                        else if (k < 16) hi |= x << (8 * (k - 8));
+                        else nx |= x << (8 * (k - 16));
+                    }
+                }
+                // a byte 0 or 1 in front, or 00 00 ff ff: positions whose first byte is neither 0x00 nor 0x01 cannot match
+#pragma unroll
+                for (unsigned k = 0; k < 16; ++k) {
+                    const unsigned long long a = k < 8 ? lo : hi, c = k < 8 ? hi : nx;
+                    const unsigned sh = 8 * (k & 7);
+                    const unsigned long long w = sh ? (a >> sh) | (c << (64 - sh)) : a;
+                    if (((uint32_t)w & 0xfeu) == 0u) test(w, b0 + k);
+                }
+            }
+            __syncthreads();
+            const uint32_t nl = nlocal;
+            __syncthreads();
+            if (nl > kFindLocal / 4) flush();
+        }
+        flush();
+        return;
+    }
     for (unsigned long long base = lo_b; base < hi_b; base += 256) {
         const unsigned long long b = base + threadIdx.x;
         if (b < hi_b && b + 8 < src_len) {
