@@ -74,6 +74,8 @@ enum ScratchSlot {
     kScrLargeRetry,         // device: worst-case slots of the parts that overflowed theirs
     kScrLargeSym,           // device: segs | copies | the stream's symbol array
     kScrLargeSrc,           // device: the compressed bytes of a large HOST-resident stream (zng_rocm_inflate_raw*)
+    kScrLargeCandHost,      // pinned: the finder's counts and the first candidates
+    kScrLargePartsHost,     // pinned: jobs | starts | results of the parts
     kScrCount
 };
 

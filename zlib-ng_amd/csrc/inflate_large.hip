@@ -447,20 +447,25 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     // bytes without a start, that is all the cutting the stream needs and the search of every bit position (F1's
     // main loop) and F2 are skipped -- 1.3 of 9.4 ms for the 256 MiB cfg3 stream of this library's level-6 class
     std::vector<unsigned long long> good;
-    uint32_t n12[2] = {0, 0};
     const uint32_t first = std::min<uint32_t>(cap2, 16384u);
+    // what comes back from and goes up to the device between the launches passes through pinned memory (pageable copies of
+    // these few hundred KiB were a good part of the 0.55 ms the host spends between the kernels of a 256 MiB stream)
+    uint8_t *hp = nullptr;
+    if (int rc = scratch_reserve(ws, kScrLargeCandHost, 64 + (size_t)first * 8, true, (void **)&hp)) return rc;
+    uint32_t *n12 = (uint32_t *)hp;
+    unsigned long long *h_good = (unsigned long long *)(hp + 64);
+    n12[0] = n12[1] = 0;
     ZR_HIP(hipMemsetAsync(d_n, 0, 8, st));
     hipLaunchKernelGGL(find_headers_kernel<true>, dim3(4096), dim3(256), 0, st, d_src, (unsigned long long)src_len, d_good, d_n + 1, cap2);
     ZR_HIP(hipGetLastError());
-    good.resize(first);
     ZR_HIP(hipMemcpyAsync(n12, d_n, 8, hipMemcpyDeviceToHost, st));
-    ZR_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)first * 8, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipMemcpyAsync(h_good, d_good, (size_t)first * 8, hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
     // ... "enough" = no stretch of more than 128 KiB without one (a count would not do: the stored blocks of one incompressible
     // region are thousands of starts and say nothing about the Huffman blocks elsewhere)
     bool patterns_do = n12[1] >= 64u && n12[1] <= first;
     if (patterns_do) {
-        good.resize(n12[1]);
+        good.assign(h_good, h_good + n12[1]);
         for (unsigned long long &b : good) b &= ~(1ull << 63);
         std::sort(good.begin(), good.end(), [](unsigned long long x, unsigned long long y) { return (x & ~(1ull << 62)) < (y & ~(1ull << 62)); });
         unsigned long long prev = 0;
@@ -470,7 +475,6 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
             prev = b;
         }
         if (8ull * src_len - prev > 8ull * (128u << 10)) patterns_do = false;
-        if (!patterns_do) good.resize(first);
     }
     if (!patterns_do) {
         ZR_HIP(hipMemsetAsync(d_n, 0, 8, st));
@@ -481,9 +485,10 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
         ZR_HIP(hipGetLastError());
         // the counts and (what is almost always all of) the list in one round trip
         ZR_HIP(hipMemcpyAsync(n12, d_n, 8, hipMemcpyDeviceToHost, st));
-        ZR_HIP(hipMemcpyAsync(good.data(), d_good, (size_t)first * 8, hipMemcpyDeviceToHost, st));
+        ZR_HIP(hipMemcpyAsync(h_good, d_good, (size_t)first * 8, hipMemcpyDeviceToHost, st));
         ZR_HIP(hipStreamSynchronize(st));
         if (n12[0] == 0 || n12[0] > cap1) return why("no candidate block starts, or far more than a deflate stream has");
+        if (n12[1] <= cap2) good.assign(h_good, h_good + std::min(n12[1], first));
     }
     const uint32_t n2 = n12[1];
     if (n2 > cap2) return why("far more valid block headers than a deflate stream has");
@@ -529,15 +534,20 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
     unsigned long long *d_starts = (unsigned long long *)(sp + jobs_b);
     uint32_t *d_res = (uint32_t *)(sp + jobs_b + starts_b);
     uint16_t *d_slots = (uint16_t *)(sp + jobs_b + starts_b + res_b);
-    std::vector<InflateJobDev> jobs(np);
+    uint8_t *hq = nullptr;
+    if (scratch_reserve(ws, kScrLargePartsHost, jobs_b + starts_b + res_b, true, (void **)&hq) != ZNG_ROCM_OK)
+        return why("no pinned memory for the part tables");
+    InflateJobDev *jobs = (InflateJobDev *)hq;
+    unsigned long long *h_starts = (unsigned long long *)(hq + jobs_b);
+    uint32_t *res = (uint32_t *)(hq + jobs_b + starts_b);
+    std::copy(starts.begin(), starts.end(), h_starts);
     for (size_t i = 0; i < np; ++i)
         jobs[i] = InflateJobDev{d_src, (uint8_t *)(d_slots + slot_off[i]), src_len, slot_off[i + 1] - slot_off[i],
                                 i == 0 ? window_len : 32768u, 0u};
-    ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
-    ZR_HIP(hipMemcpyAsync(d_starts, starts.data(), np * 8, hipMemcpyHostToDevice, st));
+    ZR_HIP(hipMemcpyAsync(d_jobs, jobs, np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
+    ZR_HIP(hipMemcpyAsync(d_starts, h_starts, np * 8, hipMemcpyHostToDevice, st));
     if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, many, st)) return rc;
-    std::vector<uint32_t> res(np * 8);
-    ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
+    ZR_HIP(hipMemcpyAsync(res, d_res, np * 32, hipMemcpyDeviceToHost, st));
     ZR_HIP(hipStreamSynchronize(st));
     // parts whose slot was too small (more than kSlotRatio : 1): once more, with room for deflate's worst case (1032 : 1)
     uint8_t *bigp = nullptr;
@@ -565,16 +575,16 @@ static int inflate_large_try(Workspace *ws, const uint8_t *d_src, size_t src_len
                 jobs[i].out_cap = capi;
                 at += capi;
             }
-            ZR_HIP(hipMemcpyAsync(d_jobs, jobs.data(), np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
+            ZR_HIP(hipMemcpyAsync(d_jobs, jobs, np * sizeof(InflateJobDev), hipMemcpyHostToDevice, st));
             if (int rc = launch_inflate_parts_device(d_jobs, np, d_res, d_starts, many, st)) return rc;
-            ZR_HIP(hipMemcpyAsync(res.data(), d_res, np * 32, hipMemcpyDeviceToHost, st));
+            ZR_HIP(hipMemcpyAsync(res, d_res, np * 32, hipMemcpyDeviceToHost, st));
             ZR_HIP(hipStreamSynchronize(st));
         }
     }
 
 #ifdef ZR_INFLATE_STATS
     g_dbg_starts = starts;
-    g_dbg_res = res;
+    g_dbg_res.assign(res, res + np * 8);
 #endif
     // ---- the chain from bit 0 -------------------------------------------------------------------------------------
     std::vector<PartCopy> copies;
