@@ -182,20 +182,28 @@ void find_headers_kernel(const uint8_t *__restrict__ src, unsigned long long src
                     if (i < kFindLocal) local[i] = (8ull * b) | (3ull << 62);          // bit 62: a stored block (light work)
                 }
             }
+            if constexpr (!PATTERNS) {
+                // the cheap header tests for the eight bit positions of this byte at once, as bit masks over the window (bit k
+                // = position k): BTYPE = 2 (bit k+1 clear, bit k+2 set), HLIT and HDIST not 30 or 31 (their upper four bits not
+                // all set); the Kraft sum only for the positions left, one by one (a wavefront executes as many turns as
+                // its busiest lane has positions left -- ~5 -- where the unrolled form executed the sum eight times)
+                const uint32_t w = (uint32_t)lo;
+                const uint32_t hl = (w >> 4) & (w >> 5) & (w >> 6) & (w >> 7), hd = (w >> 9) & (w >> 10) & (w >> 11) & (w >> 12);
+                uint32_t left = (~w >> 1) & (w >> 2) & ~hl & ~hd & 0xffu;
+                while (left) {
+                    const unsigned k = (unsigned)__builtin_ctz(left);
+                    left &= left - 1u;
+                    const unsigned long long v = k ? (lo >> k) | (hi << (64 - k)) : lo;
+                    const unsigned ncode = ((uint32_t)(v >> 13) & 15u) + 4u;
+                    unsigned long long c = (lo >> (k + 17)) | (hi << (64 - (k + 17)));       // 57 bits: all 19 fields
+                    c &= (1ull << (3 * ncode)) - 1ull;                                          // (19 fields are 57 bits: the table lookups below read 63)
+                    unsigned sum = 0;
 #pragma unroll
-            for (unsigned k = 0; k < (PATTERNS ? 0u : 8u); ++k) {
-                const unsigned long long v = k ? (lo >> k) | (hi << (64 - k)) : lo;
-                const uint32_t h = (uint32_t)v & 8191u;
-                if (((h >> 1) & 3u) != 2u || ((h >> 3) & 31u) > 29u || ((h >> 8) & 31u) > 29u) continue;
-                const unsigned ncode = ((uint32_t)(v >> 13) & 15u) + 4u;
-                unsigned long long c = (lo >> (k + 17)) | (hi << (64 - (k + 17)));       // 57 bits: all 19 fields
-                c &= (1ull << (3 * ncode)) - 1ull;                                          // (19 fields are 57 bits: the table lookups below read 63)
-                unsigned sum = 0;
-#pragma unroll
-                for (int g = 0; g < 7; ++g) sum += kraft9[(uint32_t)(c >> (9 * g)) & 511u];
-                if (sum != 128u) continue;
-                const uint32_t i = atomicAdd(&nlocal, 1u);
-                if (i < kFindLocal) local[i] = 8ull * b + k;
+                    for (int g = 0; g < 7; ++g) sum += kraft9[(uint32_t)(c >> (9 * g)) & 511u];
+                    if (sum != 128u) continue;
+                    const uint32_t i = atomicAdd(&nlocal, 1u);
+                    if (i < kFindLocal) local[i] = 8ull * b + k;
+                }
             }
         }
         // 2048 positions per round leave ~2 survivors on real data; a round of adversarial data could fill the list
